@@ -1,0 +1,183 @@
+/*
+ * mg_hip.h -- C ABI of libmg_hip: the 3-D multigrid Poisson V-cycle of
+ * jcoady/MultiGrid's PotentialSolver family as hand-written HIP kernels for
+ * AMD MI355X (gfx950).
+ *
+ * The library replaces the body of MultiGridSolver{,V2,V3,V4,V5}::solve()
+ * (reference cpp/PotentialSolver.cpp:2390-4248).  A host-side PotentialSolver
+ * subclass packs World::phi / World::rho (Field_<double>, rows of nk doubles,
+ * reference cpp/Field.h:65-70) into flat arrays with index ((i*nj)+j)*nk+k --
+ * the reference's own memory order -- and calls the functions below.
+ *
+ * Conventions
+ *   - plain C, no C++ types, nothing throws across the boundary;
+ *   - every function returns MG_OK (0) or a negative mg_status; the text of the
+ *     last failure on the calling thread is mg_last_error();
+ *   - "flat" host arrays are caller owned, fp64, ((i*nj)+j)*nk+k, k contiguous;
+ *   - a handle is bound to one HIP device and is not thread safe (the reference
+ *     solver is not re-entrant either: it mutates its members);
+ *   - the smoother is red-black Gauss-Seidel/SOR, colour (i+j+k)&1 == 0 first,
+ *     with the reference's update formula and omega; every other operator
+ *     reproduces the reference's arithmetic bit for bit (same association
+ *     order, true divisions, no FMA contraction).
+ */
+#ifndef MG_HIP_H
+#define MG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_ABI_VERSION 1
+#define MG_MAX_LEVELS 12 /* fine grid + up to 11 coarse grids */
+
+typedef enum mg_status {
+    MG_OK = 0,
+    MG_ERR_INVALID = -1,   /* bad argument (sizes, depth, null pointer) */
+    MG_ERR_HIP = -2,       /* a HIP runtime call failed */
+    MG_ERR_NOMEM = -3,     /* device or host allocation failed */
+    MG_ERR_NO_DEVICE = -4, /* no usable gfx950 device */
+    MG_ERR_STATE = -5      /* call out of order (e.g. solve before set_rho) */
+} mg_status;
+
+typedef struct mg_handle mg_handle;
+
+/* Solver description.  Replaces the constructor arguments and hard-coded
+ * constants of the reference classes:
+ *   n, dh   World::ni,nj,nk and World::getDh()          (cpp/World.h:50,92)
+ *   depth   number of coarse grids: 1 = MultiGridSolver, 2 = V2, ... 5 = V5
+ *           (cpp/PotentialSolver.h:171-272); level l has n>>l nodes per axis
+ *   nu      sweeps per level, nu[0] on the fine grid, nu[depth] on the coarsest
+ *           (cpp/PotentialSolver.cpp:2422-2425, :2629-2634, :2922-2929,
+ *            :3298-3307, :3759-3770)
+ *   omega   SOR factor, 1.4 in the reference (cpp/PotentialSolver.cpp:3786)
+ *   device  HIP device ordinal */
+typedef struct mg_config {
+    int64_t n[3];
+    double dh[3];
+    int32_t depth;
+    int32_t nu[MG_MAX_LEVELS];
+    double omega;
+    int32_t device;
+    int32_t reserved;
+} mg_config;
+
+/* Accumulated device time per operator, measured with HIP events on the
+ * handle's stream while profiling is on (mg_set_profiling).  Index with
+ * mg_timer_kind. */
+typedef enum mg_timer_kind {
+    MG_T_SMOOTH_FINE = 0, /* fine-level smoother launches */
+    MG_T_RESIDUAL,        /* fine residual (+ sum of squares) */
+    MG_T_RESTRICT,        /* all restriction launches */
+    MG_T_SMOOTH_COARSE,   /* all coarse-level smoother launches */
+    MG_T_PROLONG,         /* coarse-to-coarse prolongations */
+    MG_T_PROLONG_CORRECT, /* fine prolongation fused with phi -= eps */
+    MG_T_NORM,            /* final reduction of the partial sums */
+    MG_T_COUNT
+} mg_timer_kind;
+
+typedef struct mg_timers {
+    double ms[MG_T_COUNT];       /* summed kernel time, milliseconds */
+    uint64_t launches[MG_T_COUNT];
+    double bytes[MG_T_COUNT];    /* summed algorithmic bytes of those launches */
+} mg_timers;
+
+/* ---- library ---------------------------------------------------------- */
+int mg_abi_version(void);
+const char *mg_last_error(void);
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int mg_device_count(void);
+
+/* ---- solver object: replaces `new MultiGridSolverVn(world, max_it, tol)` and
+ * its members R_h, R_2h.., eps_h, eps_2h.. (cpp/PotentialSolver.h:188-270,
+ * cpp/Main.cpp:88-100) ---------------------------------------------------- */
+/* Fills cfg with the reference schedule for `depth` (1..5 as the classes;
+ * deeper: 1 fine sweep, 5 per intermediate level, 50 on the coarsest). */
+int mg_default_config(mg_config *cfg, int64_t ni, int64_t nj, int64_t nk,
+                      const double dh[3], int depth);
+int mg_create(const mg_config *cfg, mg_handle **out);
+int mg_destroy(mg_handle *h);
+
+/* world.rho -> device (stored as rho/EPS_0, the only form the path uses;
+ * cpp/PotentialSolver.cpp:3780,:3800). */
+int mg_set_rho(mg_handle *h, const double *rho_flat);
+/* world.phi -> device: initial guess and Dirichlet face values
+ * (cpp/World.cpp:40-52). */
+int mg_set_phi(mg_handle *h, const double *phi_flat);
+/* device -> world.phi */
+int mg_get_phi(mg_handle *h, double *phi_flat);
+
+/* The iteration loop of solve() (cpp/PotentialSolver.cpp:3756-4216): at most
+ * max_it cycles; stops in the first cycle whose residual norm
+ * sqrt(sum(R_h^2)/(ni*nj*nk)) is < tol, after smoothing and before that cycle's
+ * coarse-grid correction, exactly like the reference.  *converged = 1/0,
+ * *cycles = residual evaluations performed, *L2 = last norm.  A solve that
+ * does not converge is not an error (the reference prints to cerr and returns
+ * false, cpp/PotentialSolver.cpp:4246-4247); the host adapter prints. */
+int mg_solve(mg_handle *h, unsigned max_it, double tol, int *converged,
+             unsigned *cycles, double *L2);
+/* One full iteration including the correction (no termination test), for
+ * benchmarking; *L2 = norm observed after this cycle's smoothing. */
+int mg_vcycle(mg_handle *h, double *L2);
+/* `count` iterations back to back with no host synchronisation in between;
+ * *L2 = norm observed in the last one. */
+int mg_vcycles(mg_handle *h, unsigned count, double *L2);
+/* Zero R_l and eps_l: the state of a freshly constructed reference solver
+ * (cpp/Field.h:72).  The reference never does this after construction. */
+int mg_reset_state(mg_handle *h);
+
+/* Copy a level's work array to the host, for state comparison with the
+ * reference members.  which: 0 = R_l (dims n>>l), 1 = eps_l (dims (n>>l)+1 for
+ * l >= 1; eps_0 does not exist on the device, the fine prolongation is fused
+ * with the correction).  dims_out receives the array dims. */
+int mg_get_level_array(mg_handle *h, int which, int level, double *out_flat,
+                       int64_t dims_out[3]);
+
+int mg_set_profiling(mg_handle *h, int on);
+int mg_get_timers(mg_handle *h, mg_timers *out);
+int mg_reset_timers(mg_handle *h);
+/* Device time of the last mg_vcycles()/mg_vcycle() call in milliseconds
+ * (HIP events on the handle's stream around the whole call). */
+int mg_last_call_ms(mg_handle *h, double *ms);
+
+/* ---- single operators on caller-supplied flat host arrays ---------------
+ * Test entry points: each uploads its inputs, runs the same kernel the solver
+ * uses, downloads the result.  `device` is the HIP ordinal. */
+
+/* R = A*phi - rho/EPS_0 inside, R = phi on the six faces; *sumsq = sum R^2
+ * (cpp/PotentialSolver.cpp:3792-3816). */
+int mg_op_residual(int device, const int64_t n[3], const double dh[3],
+                   const double *phi, const double *rho, double *R_out,
+                   double *sumsq);
+/* 27-point full weighting, injection where an index is 0
+ * (cpp/PotentialSolver.cpp:3822-3839).  R_coarse has dims n_fine>>1 and is
+ * read-modify-written: entries the loop does not reach keep their values. */
+int mg_op_restrict27(int device, const int64_t n_fine[3], const double *R_fine,
+                     double *R_coarse);
+/* Trilinear prolongation, overwriting eps_fine on 0..n-2 per axis
+ * (cpp/PotentialSolver.cpp:4170-4206).  n = size of the fine level (loop
+ * bound), fine_dims = dims of eps_fine (n for the finest level, n+1 for a
+ * coarse level), coarse dims = (n>>1)+1. */
+int mg_op_prolong(int device, const int64_t n[3], const int64_t fine_dims[3],
+                  const double *eps_coarse, double *eps_fine);
+/* phi -= eps (cpp/PotentialSolver.cpp:4209-4214). */
+int mg_op_correct(int device, int64_t count, double *phi, const double *eps);
+/* Fused fine prolongation + correction: phi -= P(eps_coarse). */
+int mg_op_prolong_correct(int device, const int64_t n[3], const double *eps_coarse,
+                          double *phi);
+/* Red-black GS-SOR sweeps on u (dims u_dims) with right-hand side rhs (dims
+ * rhs_dims) over 1..n-2 per axis; c = {cx,cy,cz}; rhs_is_rho != 0 divides rhs by
+ * EPS_0 first (the fine-level form, cpp/PotentialSolver.cpp:3780-3786; coarse
+ * form :3929-3935). */
+int mg_op_smooth_rb(int device, const int64_t n[3], const int64_t u_dims[3],
+                    const int64_t rhs_dims[3], const double c[3], double omega,
+                    int sweeps, int rhs_is_rho, const double *rhs, double *u);
+/* sum of x[p]^2 (cpp/PotentialSolver.cpp:3810-3816) */
+int mg_op_sumsq(int device, int64_t count, const double *x, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MG_HIP_H */

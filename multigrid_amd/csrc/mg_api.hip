@@ -1,0 +1,718 @@
+// C ABI of libmg_hip (declared in include/mg_hip.h): solver handle, cycle
+// driver and the single-operator test entry points.
+#include "../../include/mg_hip.h"
+#include "mg_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using mgk::Coef;
+using mgk::View;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? MG_ERR_NOMEM : MG_ERR_HIP, "%s: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                   \
+    } while (0)
+
+int select_device(int device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(MG_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= count)
+        return fail(MG_ERR_INVALID, "device %d out of range (have %d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    return MG_OK;
+}
+
+// 1/(4^l dx dx) exactly as the reference writes it (cpp/PotentialSolver.cpp:3728-3750)
+Coef level_coef(const double dh[3], int level)
+{
+    double f = 1.0;
+    for (int l = 0; l < level; l++) f *= 4.0;
+    double c[3];
+    for (int a = 0; a < 3; a++) c[a] = (level == 0) ? 1.0 / (dh[a] * dh[a]) : 1.0 / (f * dh[a] * dh[a]);
+    Coef r;
+    r.cx = c[0];
+    r.cy = c[1];
+    r.cz = c[2];
+    r.d = 2 * c[0] + 2 * c[1] + 2 * c[2];
+    return r;
+}
+
+View make_view(double *p, const int64_t d[3])
+{
+    View v;
+    v.p = p;
+    for (int a = 0; a < 3; a++) v.d[a] = d[a];
+    v.sj = mgk::pitch_for(d[2]);
+    v.si = v.sj * d[1];
+    return v;
+}
+
+int alloc_view(View *v, const int64_t d[3])
+{
+    *v = make_view(nullptr, d);
+    const size_t bytes = (size_t)v->elems() * sizeof(double);
+    HIP_TRY(hipMalloc((void **)&v->p, bytes));
+    HIP_TRY(hipMemset(v->p, 0, bytes));
+    return MG_OK;
+}
+
+struct Level {
+    int64_t n[3];   // level size n_0 >> l: bounds every loop on this level
+    Coef c;
+    int nu;
+    View R;         // dims n
+    View eps;       // dims n+1 (l >= 1); unused on l == 0
+};
+
+}  // namespace
+
+struct mg_handle {
+    mg_config cfg;
+    int L;
+    Level lv[MG_MAX_LEVELS];
+    View phi, b;            // fine potential and rho/EPS_0
+    double *partials = nullptr;
+    int64_t n_partials = 0;
+    double *d_sum = nullptr;    // device scalar: sum of R_h^2
+    double *h_sum = nullptr;    // pinned host mirror
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    bool have_rho = false, have_phi = false;
+    double last_ms = 0;
+    // profiling
+    bool profiling = false;
+    struct Rec { int kind; hipEvent_t a, b; double bytes; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> ev_pool;
+    mg_timers timers;
+};
+
+namespace {
+
+int64_t count3(const int64_t d[3]) { return d[0] * d[1] * d[2]; }
+
+struct Prof {
+    mg_handle *h;
+    int kind;
+    double bytes;
+    hipEvent_t a = nullptr, b = nullptr;
+    Prof(mg_handle *h_, int kind_, double bytes_) : h(h_), kind(kind_), bytes(bytes_)
+    {
+        if (!h->profiling) return;
+        a = take();
+        b = take();
+        hipEventRecord(a, h->stream);
+    }
+    ~Prof()
+    {
+        if (!h->profiling) return;
+        hipEventRecord(b, h->stream);
+        h->recs.push_back({kind, a, b, bytes});
+    }
+    hipEvent_t take()
+    {
+        if (!h->ev_pool.empty()) {
+            hipEvent_t e = h->ev_pool.back();
+            h->ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        hipEventCreate(&e);
+        return e;
+    }
+};
+
+void drain_profile(mg_handle *h)
+{
+    if (h->recs.empty()) return;
+    hipStreamSynchronize(h->stream);
+    for (auto &r : h->recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            h->timers.ms[r.kind] += ms;
+            h->timers.launches[r.kind] += 1;
+            h->timers.bytes[r.kind] += r.bytes;
+        }
+        h->ev_pool.push_back(r.a);
+        h->ev_pool.push_back(r.b);
+    }
+    h->recs.clear();
+}
+
+// Steps 1)-2b) of the reference iteration: smooth the fine grid, residual, norm.
+// Leaves sum(R_h^2) in h->d_sum and queues its copy to h->h_sum.
+void enqueue_smooth_residual(mg_handle *h)
+{
+    Level &f = h->lv[0];
+    const double N = (double)count3(f.n);
+    for (int s = 0; s < f.nu; s++)
+        for (int colour = 0; colour < 2; colour++) {
+            Prof p(h, MG_T_SMOOTH_FINE, 16.0 * N);
+            mgk::smooth_colour(h->stream, h->phi, h->b, f.n, f.c, h->cfg.omega, colour);
+        }
+    {
+        Prof p(h, MG_T_RESIDUAL, 24.0 * N);
+        mgk::residual(h->stream, h->phi, h->b, f.R, f.c, h->partials);
+    }
+    {
+        Prof p(h, MG_T_NORM, 8.0 * (double)h->n_partials);
+        mgk::sum_partials(h->stream, h->partials, h->n_partials, h->d_sum);
+    }
+    hipMemcpyAsync(h->h_sum, h->d_sum, sizeof(double), hipMemcpyDeviceToHost, h->stream);
+}
+
+// Steps 3)-6): restrict down, (smooth, prolong) up, correct.
+void enqueue_coarse_correction(mg_handle *h)
+{
+    const int L = h->L;
+    for (int l = 0; l < L; l++) {
+        Prof p(h, MG_T_RESTRICT, 9.0 * (double)count3(h->lv[l].n));
+        mgk::restrict27(h->stream, h->lv[l].R, h->lv[l + 1].R);
+    }
+    for (int l = L; l >= 1; l--) {
+        Level &v = h->lv[l];
+        if (l < L) {
+            Prof p(h, MG_T_PROLONG, 9.0 * (double)count3(v.n));
+            mgk::prolong(h->stream, h->lv[l + 1].eps, v.eps, v.n);
+        }
+        for (int s = 0; s < v.nu; s++)
+            for (int colour = 0; colour < 2; colour++) {
+                Prof p(h, MG_T_SMOOTH_COARSE, 16.0 * (double)count3(v.n));
+                mgk::smooth_colour(h->stream, v.eps, v.R, v.n, v.c, h->cfg.omega, colour);
+            }
+    }
+    {
+        Prof p(h, MG_T_PROLONG_CORRECT, 17.0 * (double)count3(h->lv[0].n));
+        mgk::prolong_correct(h->stream, h->lv[1].eps, h->phi, h->lv[0].n);
+    }
+}
+
+double l2_from_sum(const mg_handle *h, double sum)
+{
+    // sqrt(sum/(ni*nj*nk)) -- reference cpp/PotentialSolver.cpp:3818, with a 64-bit count
+    return std::sqrt(sum / (double)count3(h->lv[0].n));
+}
+
+int check_ready(mg_handle *h)
+{
+    if (!h) return fail(MG_ERR_INVALID, "null handle");
+    if (!h->have_rho || !h->have_phi)
+        return fail(MG_ERR_STATE, "mg_set_rho and mg_set_phi must be called before solving");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    return MG_OK;
+}
+
+// dense host array (row length d[2]) <-> pitched device array
+int h2d(View dst, const double *flat, hipStream_t s)
+{
+    const size_t row = (size_t)dst.d[2] * sizeof(double);
+    HIP_TRY(hipMemcpy2DAsync(dst.p, (size_t)dst.sj * sizeof(double), flat, row, row,
+                             (size_t)(dst.d[0] * dst.d[1]), hipMemcpyHostToDevice, s));
+    return MG_OK;
+}
+
+int d2h(double *flat, View src, hipStream_t s)
+{
+    const size_t row = (size_t)src.d[2] * sizeof(double);
+    HIP_TRY(hipMemcpy2DAsync(flat, row, src.p, (size_t)src.sj * sizeof(double), row,
+                             (size_t)(src.d[0] * src.d[1]), hipMemcpyDeviceToHost, s));
+    return MG_OK;
+}
+
+int upload(mg_handle *h, const double *flat, View dst, bool div_eps0)
+{
+    int rc = h2d(dst, flat, h->stream);
+    if (rc) return rc;
+    if (div_eps0) {
+        mgk::div_eps0(h->stream, dst);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mg_abi_version(void) { return MG_ABI_VERSION; }
+
+const char *mg_last_error(void) { return g_err; }
+
+int mg_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+int mg_default_config(mg_config *cfg, int64_t ni, int64_t nj, int64_t nk, const double dh[3], int depth)
+{
+    if (!cfg || !dh) return fail(MG_ERR_INVALID, "null argument");
+    if (depth < 1 || depth >= MG_MAX_LEVELS) return fail(MG_ERR_INVALID, "depth %d out of range 1..%d", depth, MG_MAX_LEVELS - 1);
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->n[0] = ni;
+    cfg->n[1] = nj;
+    cfg->n[2] = nk;
+    for (int a = 0; a < 3; a++) cfg->dh[a] = dh[a];
+    cfg->depth = depth;
+    cfg->omega = 1.4;
+    // fine sweeps: 3 for depth 1..4, 1 for depth >= 5; 5 on intermediate levels,
+    // 50 on the coarsest (reference cpp/PotentialSolver.cpp:2422-2425 ... :3759-3770)
+    cfg->nu[0] = depth >= 5 ? 1 : 3;
+    for (int l = 1; l < depth; l++) cfg->nu[l] = 5;
+    cfg->nu[depth] = 50;
+    return MG_OK;
+}
+
+int mg_create(const mg_config *cfg, mg_handle **out)
+{
+    if (!cfg || !out) return fail(MG_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const int L = cfg->depth;
+    if (L < 1 || L >= MG_MAX_LEVELS) return fail(MG_ERR_INVALID, "depth %d out of range 1..%d", L, MG_MAX_LEVELS - 1);
+    for (int a = 0; a < 3; a++) {
+        if (cfg->n[a] < 3 || cfg->n[a] > (int64_t)1 << 20) return fail(MG_ERR_INVALID, "n[%d]=%lld out of range", a, (long long)cfg->n[a]);
+        if ((cfg->n[a] >> L) < 3) return fail(MG_ERR_INVALID, "n[%d]=%lld too small for depth %d (coarsest level needs >= 3 nodes)", a, (long long)cfg->n[a], L);
+        if (!(cfg->dh[a] > 0)) return fail(MG_ERR_INVALID, "dh[%d] must be positive", a);
+    }
+    for (int l = 0; l <= L; l++)
+        if (cfg->nu[l] < 0 || cfg->nu[l] > 100000) return fail(MG_ERR_INVALID, "nu[%d]=%d out of range", l, cfg->nu[l]);
+    int rc = select_device(cfg->device);
+    if (rc) return rc;
+
+    mg_handle *h = new (std::nothrow) mg_handle();
+    if (!h) return fail(MG_ERR_NOMEM, "host allocation failed");
+    h->cfg = *cfg;
+    h->L = L;
+    memset(&h->timers, 0, sizeof(h->timers));
+    memset(h->lv, 0, sizeof(h->lv));
+#define CREATE_TRY(expr)          \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_) {                \
+            mg_destroy(h);        \
+            return rc_;           \
+        }                         \
+    } while (0)
+    auto hip_try = [](hipError_t e, const char *what) -> int {
+        if (e == hipSuccess) return MG_OK;
+        return fail(e == hipErrorOutOfMemory ? MG_ERR_NOMEM : MG_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    };
+    CREATE_TRY(hip_try(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate"));
+    CREATE_TRY(hip_try(hipEventCreate(&h->ev_a), "hipEventCreate"));
+    CREATE_TRY(hip_try(hipEventCreate(&h->ev_b), "hipEventCreate"));
+    for (int l = 0; l <= L; l++) {
+        Level &v = h->lv[l];
+        int64_t en[3];
+        for (int a = 0; a < 3; a++) {
+            v.n[a] = cfg->n[a] >> l;
+            en[a] = v.n[a] + 1;
+        }
+        v.c = level_coef(cfg->dh, l);
+        v.nu = cfg->nu[l];
+        CREATE_TRY(alloc_view(&v.R, v.n));
+        if (l >= 1) CREATE_TRY(alloc_view(&v.eps, en));
+    }
+    CREATE_TRY(alloc_view(&h->phi, h->lv[0].n));
+    CREATE_TRY(alloc_view(&h->b, h->lv[0].n));
+    h->n_partials = mgk::residual_partials(h->lv[0].n);
+    CREATE_TRY(hip_try(hipMalloc((void **)&h->partials, (size_t)h->n_partials * sizeof(double)), "hipMalloc(partials)"));
+    CREATE_TRY(hip_try(hipMalloc((void **)&h->d_sum, sizeof(double)), "hipMalloc(sum)"));
+    CREATE_TRY(hip_try(hipHostMalloc((void **)&h->h_sum, sizeof(double), hipHostMallocDefault), "hipHostMalloc"));
+    *h->h_sum = 0;
+#undef CREATE_TRY
+    *out = h;
+    return MG_OK;
+}
+
+int mg_destroy(mg_handle *h)
+{
+    if (!h) return MG_OK;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (auto &r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto e : h->ev_pool) hipEventDestroy(e);
+    for (int l = 0; l < MG_MAX_LEVELS; l++) {
+        if (h->lv[l].R.p) hipFree(h->lv[l].R.p);
+        if (h->lv[l].eps.p) hipFree(h->lv[l].eps.p);
+    }
+    if (h->phi.p) hipFree(h->phi.p);
+    if (h->b.p) hipFree(h->b.p);
+    if (h->partials) hipFree(h->partials);
+    if (h->d_sum) hipFree(h->d_sum);
+    if (h->h_sum) hipHostFree(h->h_sum);
+    if (h->ev_a) hipEventDestroy(h->ev_a);
+    if (h->ev_b) hipEventDestroy(h->ev_b);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return MG_OK;
+}
+
+int mg_set_rho(mg_handle *h, const double *rho_flat)
+{
+    if (!h || !rho_flat) return fail(MG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int rc = upload(h, rho_flat, h->b, true);
+    if (rc) return rc;
+    h->have_rho = true;
+    return MG_OK;
+}
+
+int mg_set_phi(mg_handle *h, const double *phi_flat)
+{
+    if (!h || !phi_flat) return fail(MG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int rc = upload(h, phi_flat, h->phi, false);
+    if (rc) return rc;
+    h->have_phi = true;
+    return MG_OK;
+}
+
+int mg_get_phi(mg_handle *h, double *phi_flat)
+{
+    if (!h || !phi_flat) return fail(MG_ERR_INVALID, "null argument");
+    if (!h->have_phi) return fail(MG_ERR_STATE, "no phi on the device yet");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int rc = d2h(phi_flat, h->phi, h->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MG_OK;
+}
+
+int mg_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsigned *cycles, double *L2)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    bool conv = false;
+    double l2 = 0;
+    unsigned it = 0;
+    HIP_TRY(hipEventRecord(h->ev_a, h->stream));
+    for (it = 0; it < max_it; it++) {
+        enqueue_smooth_residual(h);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        l2 = l2_from_sum(h, *h->h_sum);
+        if (l2 < tol) {
+            conv = true;
+            it++;
+            break;
+        }
+        enqueue_coarse_correction(h);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(h->ev_b, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    h->last_ms = ms;
+    if (converged) *converged = conv ? 1 : 0;
+    if (cycles) *cycles = it;
+    if (L2) *L2 = l2;
+    return MG_OK;
+}
+
+int mg_vcycles(mg_handle *h, unsigned count, double *L2)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev_a, h->stream));
+    for (unsigned it = 0; it < count; it++) {
+        enqueue_smooth_residual(h);
+        enqueue_coarse_correction(h);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_b, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    h->last_ms = ms;
+    if (L2) *L2 = count ? l2_from_sum(h, *h->h_sum) : 0.0;
+    return MG_OK;
+}
+
+int mg_vcycle(mg_handle *h, double *L2) { return mg_vcycles(h, 1, L2); }
+
+int mg_reset_state(mg_handle *h)
+{
+    if (!h) return fail(MG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    for (int l = 0; l <= h->L; l++) {
+        HIP_TRY(hipMemsetAsync(h->lv[l].R.p, 0, (size_t)h->lv[l].R.elems() * sizeof(double), h->stream));
+        if (l >= 1) HIP_TRY(hipMemsetAsync(h->lv[l].eps.p, 0, (size_t)h->lv[l].eps.elems() * sizeof(double), h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MG_OK;
+}
+
+int mg_get_level_array(mg_handle *h, int which, int level, double *out_flat, int64_t dims_out[3])
+{
+    if (!h || !out_flat) return fail(MG_ERR_INVALID, "null argument");
+    if (level < 0 || level > h->L) return fail(MG_ERR_INVALID, "level %d out of range", level);
+    if (which != 0 && which != 1) return fail(MG_ERR_INVALID, "which must be 0 (R) or 1 (eps)");
+    if (which == 1 && level == 0) return fail(MG_ERR_INVALID, "eps_0 is not materialised on the device");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    View src = which == 0 ? h->lv[level].R : h->lv[level].eps;
+    int rc = d2h(out_flat, src, h->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (dims_out)
+        for (int a = 0; a < 3; a++) dims_out[a] = src.d[a];
+    return MG_OK;
+}
+
+int mg_set_profiling(mg_handle *h, int on)
+{
+    if (!h) return fail(MG_ERR_INVALID, "null handle");
+    drain_profile(h);
+    h->profiling = on != 0;
+    return MG_OK;
+}
+
+int mg_get_timers(mg_handle *h, mg_timers *out)
+{
+    if (!h || !out) return fail(MG_ERR_INVALID, "null argument");
+    drain_profile(h);
+    *out = h->timers;
+    return MG_OK;
+}
+
+int mg_reset_timers(mg_handle *h)
+{
+    if (!h) return fail(MG_ERR_INVALID, "null handle");
+    drain_profile(h);
+    memset(&h->timers, 0, sizeof(h->timers));
+    return MG_OK;
+}
+
+int mg_last_call_ms(mg_handle *h, double *ms)
+{
+    if (!h || !ms) return fail(MG_ERR_INVALID, "null argument");
+    *ms = h->last_ms;
+    return MG_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* single operators on host arrays                                           */
+
+namespace {
+
+// Device buffers of one test call; freed on scope exit.
+struct Scratch {
+    std::vector<void *> ptrs;
+    ~Scratch()
+    {
+        for (void *p : ptrs) hipFree(p);
+    }
+    int view(View *v, const int64_t d[3], const double *host_flat)
+    {
+        int rc = alloc_view(v, d);
+        if (rc) return rc;
+        ptrs.push_back(v->p);
+        if (host_flat) {
+            rc = h2d(*v, host_flat, nullptr);
+            if (rc) return rc;
+            HIP_TRY(hipDeviceSynchronize());
+        }
+        return MG_OK;
+    }
+    int flat(double **p, int64_t count, const double *host)
+    {
+        HIP_TRY(hipMalloc((void **)p, (size_t)count * sizeof(double)));
+        ptrs.push_back(*p);
+        if (host) HIP_TRY(hipMemcpy(*p, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+        return MG_OK;
+    }
+    int download(View v, double *host_flat)
+    {
+        int rc = d2h(host_flat, v, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        return MG_OK;
+    }
+};
+
+int check_dims(const int64_t n[3], const char *what, int64_t lo)
+{
+    if (!n) return fail(MG_ERR_INVALID, "%s: null dims", what);
+    for (int a = 0; a < 3; a++)
+        if (n[a] < lo || n[a] > (int64_t)1 << 20) return fail(MG_ERR_INVALID, "%s: dim %d = %lld out of range", what, a, (long long)n[a]);
+    return MG_OK;
+}
+
+#define TRY(expr)           \
+    do {                    \
+        int rc_ = (expr);   \
+        if (rc_) return rc_; \
+    } while (0)
+
+int reduce_to_host(double *partials, int64_t count, double *out)
+{
+    double *d_sum = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_sum, sizeof(double)));
+    mgk::sum_partials(nullptr, partials, count, d_sum);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, d_sum, sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(d_sum);
+    HIP_TRY(e);
+    return MG_OK;
+}
+
+}  // namespace
+
+int mg_op_residual(int device, const int64_t n[3], const double dh[3], const double *phi,
+                   const double *rho, double *R_out, double *sumsq)
+{
+    if (!dh || !phi || !rho || !R_out) return fail(MG_ERR_INVALID, "null argument");
+    TRY(check_dims(n, "mg_op_residual", 3));
+    TRY(select_device(device));
+    Scratch sc;
+    View vphi, vb, vR;
+    TRY(sc.view(&vphi, n, phi));
+    TRY(sc.view(&vb, n, rho));
+    mgk::div_eps0(nullptr, vb);  // b = rho/EPS_0
+    TRY(sc.view(&vR, n, nullptr));
+    double *partials = nullptr;
+    const int64_t np = mgk::residual_partials(n);
+    TRY(sc.flat(&partials, np, nullptr));
+    mgk::residual(nullptr, vphi, vb, vR, level_coef(dh, 0), partials);
+    HIP_TRY(hipGetLastError());
+    double s = 0;
+    TRY(reduce_to_host(partials, np, &s));
+    if (sumsq) *sumsq = s;
+    return sc.download(vR, R_out);
+}
+
+int mg_op_restrict27(int device, const int64_t n_fine[3], const double *R_fine, double *R_coarse)
+{
+    if (!R_fine || !R_coarse) return fail(MG_ERR_INVALID, "null argument");
+    TRY(check_dims(n_fine, "mg_op_restrict27", 2));
+    TRY(select_device(device));
+    int64_t nc[3];
+    for (int a = 0; a < 3; a++) nc[a] = n_fine[a] >> 1;
+    Scratch sc;
+    View vf, vc;
+    TRY(sc.view(&vf, n_fine, R_fine));
+    TRY(sc.view(&vc, nc, R_coarse));
+    mgk::restrict27(nullptr, vf, vc);
+    HIP_TRY(hipGetLastError());
+    return sc.download(vc, R_coarse);
+}
+
+int mg_op_prolong(int device, const int64_t n[3], const int64_t fine_dims[3], const double *eps_coarse,
+                  double *eps_fine)
+{
+    if (!eps_coarse || !eps_fine) return fail(MG_ERR_INVALID, "null argument");
+    TRY(check_dims(n, "mg_op_prolong", 2));
+    TRY(check_dims(fine_dims, "mg_op_prolong", 2));
+    for (int a = 0; a < 3; a++)
+        if (fine_dims[a] < n[a]) return fail(MG_ERR_INVALID, "mg_op_prolong: fine_dims[%d] < n[%d]", a, a);
+    TRY(select_device(device));
+    int64_t cd[3];
+    for (int a = 0; a < 3; a++) cd[a] = (n[a] >> 1) + 1;
+    Scratch sc;
+    View vc, vf;
+    TRY(sc.view(&vc, cd, eps_coarse));
+    TRY(sc.view(&vf, fine_dims, eps_fine));
+    mgk::prolong(nullptr, vc, vf, n);
+    HIP_TRY(hipGetLastError());
+    return sc.download(vf, eps_fine);
+}
+
+int mg_op_correct(int device, int64_t count, double *phi, const double *eps)
+{
+    if (!phi || !eps || count < 0) return fail(MG_ERR_INVALID, "bad argument");
+    TRY(select_device(device));
+    if (count == 0) return MG_OK;
+    Scratch sc;
+    double *dphi = nullptr, *deps = nullptr;
+    TRY(sc.flat(&dphi, count, phi));
+    TRY(sc.flat(&deps, count, eps));
+    mgk::correct(nullptr, dphi, deps, count);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(phi, dphi, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    return MG_OK;
+}
+
+int mg_op_prolong_correct(int device, const int64_t n[3], const double *eps_coarse, double *phi)
+{
+    if (!eps_coarse || !phi) return fail(MG_ERR_INVALID, "null argument");
+    TRY(check_dims(n, "mg_op_prolong_correct", 2));
+    TRY(select_device(device));
+    int64_t cd[3];
+    for (int a = 0; a < 3; a++) cd[a] = (n[a] >> 1) + 1;
+    Scratch sc;
+    View vc, vphi;
+    TRY(sc.view(&vc, cd, eps_coarse));
+    TRY(sc.view(&vphi, n, phi));
+    mgk::prolong_correct(nullptr, vc, vphi, n);
+    HIP_TRY(hipGetLastError());
+    return sc.download(vphi, phi);
+}
+
+int mg_op_smooth_rb(int device, const int64_t n[3], const int64_t u_dims[3], const int64_t rhs_dims[3],
+                    const double c[3], double omega, int sweeps, int rhs_is_rho, const double *rhs,
+                    double *u)
+{
+    if (!c || !rhs || !u || sweeps < 0) return fail(MG_ERR_INVALID, "bad argument");
+    TRY(check_dims(n, "mg_op_smooth_rb", 3));
+    TRY(check_dims(u_dims, "mg_op_smooth_rb", 3));
+    TRY(check_dims(rhs_dims, "mg_op_smooth_rb", 3));
+    for (int a = 0; a < 3; a++)
+        if (u_dims[a] < n[a] || rhs_dims[a] < n[a]) return fail(MG_ERR_INVALID, "mg_op_smooth_rb: array dims smaller than n");
+    TRY(select_device(device));
+    Scratch sc;
+    View vu, vr;
+    TRY(sc.view(&vu, u_dims, u));
+    TRY(sc.view(&vr, rhs_dims, rhs));
+    if (rhs_is_rho) mgk::div_eps0(nullptr, vr);
+    Coef k;
+    k.cx = c[0];
+    k.cy = c[1];
+    k.cz = c[2];
+    k.d = 2 * c[0] + 2 * c[1] + 2 * c[2];
+    for (int s = 0; s < sweeps; s++)
+        for (int colour = 0; colour < 2; colour++) mgk::smooth_colour(nullptr, vu, vr, n, k, omega, colour);
+    HIP_TRY(hipGetLastError());
+    return sc.download(vu, u);
+}
+
+int mg_op_sumsq(int device, int64_t count, const double *x, double *out)
+{
+    if (!x || !out || count < 0) return fail(MG_ERR_INVALID, "bad argument");
+    TRY(select_device(device));
+    if (count == 0) { *out = 0; return MG_OK; }
+    Scratch sc;
+    double *dx = nullptr, *partials = nullptr;
+    TRY(sc.flat(&dx, count, x));
+    const int64_t np = mgk::sumsq_partials(count);
+    TRY(sc.flat(&partials, np, nullptr));
+    mgk::sumsq(nullptr, dx, count, partials);
+    HIP_TRY(hipGetLastError());
+    return reduce_to_host(partials, np, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+// gfx950 kernels of the multigrid V-cycle.  Built with -ffp-contract=off: every
+// expression below is evaluated in the association order written, with one
+// rounding per operation and true fp64 divisions, so results are bit-identical
+// to the scalar CPU evaluation of the same expressions.
+//
+// Thread mapping used throughout: the 64 lanes of a wavefront run along k (the
+// contiguous axis), a 256-thread workgroup covers 4 rows in j, blockIdx.z (or a
+// march inside the kernel) covers i.
+#include "mg_kernels.h"
+
+namespace mgk {
+
+namespace {
+
+constexpr int kBX = 64;  // lanes along k
+constexpr int kBY = 4;   // rows along j per workgroup
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum over a workgroup of up to 1024 threads; result valid in thread 0.
+// Fixed order: lanes by shuffle tree, then waves 0..nw-1 left to right.
+__device__ __forceinline__ double block_sum(double v, double *lds)
+{
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+    v = wave_sum(v);
+    if ((tid & 63) == 0) lds[tid >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    if (tid == 0)
+        for (int w = 0; w < nw; w++) t += lds[w];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void k_div_eps0(View v)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBX + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.y * kBY + threadIdx.y;
+    const int64_t i = blockIdx.z;
+    if (k >= v.d[2] || j >= v.d[1]) return;
+    double *p = v.p + v.at(i, j, k);
+    p[0] = p[0] / kEps0;
+}
+
+// One colour of GS-SOR.  u_new = u + omega*(g - u),
+// g = (((b + cx*(u[i-1]+u[i+1])) + cy*(u[j-1]+u[j+1])) + cz*(u[k-1]+u[k+1])) / d
+// (reference cpp/PotentialSolver.cpp:3780-3786 and :3929-3935).
+__global__ __launch_bounds__(256) void k_smooth_colour(View u, View rhs, int64_t nj, int64_t nk,
+                                                       Coef c, double omega, int colour)
+{
+    const int64_t i = 1 + (int64_t)blockIdx.z;
+    const int64_t j = 1 + (int64_t)blockIdx.y * kBY + threadIdx.y;
+    const int64_t m = (int64_t)blockIdx.x * kBX + threadIdx.x;
+    const int64_t k = 1 + ((i + j + 1 + colour) & 1) + 2 * m;
+    if (j > nj - 2 || k > nk - 2) return;
+    double *p = u.p + u.at(i, j, k);
+    const double b = rhs.p[rhs.at(i, j, k)];
+    const double g = (b + c.cx * (p[-u.si] + p[u.si]) + c.cy * (p[-u.sj] + p[u.sj]) +
+                      c.cz * (p[-1] + p[1])) / c.d;
+    const double u0 = p[0];
+    p[0] = u0 + omega * (g - u0);
+}
+
+// Residual (reference cpp/PotentialSolver.cpp:3792-3805) with the workgroup's
+// sum of squares written to partials[linear block id].
+__global__ __launch_bounds__(256) void k_residual(View phi, View b, View R, Coef c,
+                                                  double *__restrict__ partials)
+{
+    __shared__ double lds[4];
+    const int64_t ni = phi.d[0], nj = phi.d[1], nk = phi.d[2];
+    const int64_t k = (int64_t)blockIdx.x * kBX + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.y * kBY + threadIdx.y;
+    const int64_t i = blockIdx.z;
+    double r = 0;
+    if (k < nk && j < nj) {
+        const double *p = phi.p + phi.at(i, j, k);
+        if (i == 0 || i == ni - 1 || j == 0 || j == nj - 1 || k == 0 || k == nk - 1)
+            r = p[0] - 0;
+        else
+            r = p[0] * c.d - b.p[b.at(i, j, k)] - c.cx * (p[-phi.si] + p[phi.si]) -
+                c.cy * (p[-phi.sj] + p[phi.sj]) - c.cz * (p[-1] + p[1]);
+        R.p[R.at(i, j, k)] = r;
+    }
+    const double t = block_sum(r * r, lds);
+    if (threadIdx.x == 0 && threadIdx.y == 0)
+        partials[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(1024) void k_sum_partials(const double *__restrict__ partials,
+                                                       int64_t count, double *__restrict__ out)
+{
+    __shared__ double lds[16];
+    double v = 0;
+    for (int64_t p = threadIdx.x; p < count; p += 1024) v += partials[p];
+    const double t = block_sum(v, lds);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+__global__ __launch_bounds__(256) void k_sumsq(const double *__restrict__ x, int64_t count,
+                                               double *__restrict__ partials)
+{
+    __shared__ double lds[4];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    double v = 0;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < count; p += stride) v += x[p] * x[p];
+    const double t = block_sum(v, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// 27-point full weighting (reference cpp/PotentialSolver.cpp:3822-3839): terms
+// summed left to right, first index fastest, third slowest, then / 64.0.
+__global__ __launch_bounds__(256) void k_restrict27(View Rf, View Rc)
+{
+    const int64_t K = (int64_t)blockIdx.x * kBX + threadIdx.x;
+    const int64_t J = (int64_t)blockIdx.y * kBY + threadIdx.y;
+    const int64_t I = blockIdx.z;
+    if (K >= Rc.d[2] || J >= Rc.d[1]) return;
+    const double *f = Rf.p + Rf.at(2 * I, 2 * J, 2 * K);
+    double v;
+    if (I == 0 || J == 0 || K == 0) {
+        v = f[0];
+    } else {
+        const int64_t si = Rf.si, sj = Rf.sj;
+#define F(di, dj, dk) f[(di) * si + (dj) * sj + (dk)]
+        v = F(-1, -1, -1) + 2 * F(0, -1, -1) + F(1, -1, -1) +
+            2 * F(-1, 0, -1) + 4 * F(0, 0, -1) + 2 * F(1, 0, -1) +
+            F(-1, 1, -1) + 2 * F(0, 1, -1) + F(1, 1, -1) +
+            2 * F(-1, -1, 0) + 4 * F(0, -1, 0) + 2 * F(1, -1, 0) +
+            4 * F(-1, 0, 0) + 8 * F(0, 0, 0) + 4 * F(1, 0, 0) +
+            2 * F(-1, 1, 0) + 4 * F(0, 1, 0) + 2 * F(1, 1, 0) +
+            F(-1, -1, 1) + 2 * F(0, -1, 1) + F(1, -1, 1) +
+            2 * F(-1, 0, 1) + 4 * F(0, 0, 1) + 2 * F(1, 0, 1) +
+            F(-1, 1, 1) + 2 * F(0, 1, 1) + F(1, 1, 1);
+#undef F
+        v = v / 64.0;
+    }
+    Rc.p[Rc.at(I, J, K)] = v;
+}
+
+// Trilinear interpolant of ec at fine node (i,j,k), none of the indices 0
+// (reference cpp/PotentialSolver.cpp:4176-4205).  The eight parity cases share
+// their leading partial sums, so they fold into: a = sum over the K plane in the
+// reference's order, then (k odd) the K+1 plane's terms appended in that order.
+__device__ __forceinline__ double interp(const View &ec, int64_t i, int64_t j, int64_t k)
+{
+    const double *c = ec.p + ec.at(i >> 1, j >> 1, k >> 1);
+    const int64_t si = ec.si, sj = ec.sj;
+    const bool oi = i & 1, oj = j & 1, ok = k & 1;
+    double a = c[0];
+    double w = 1.0;
+    if (oi) { a = a + c[si]; w = 0.5; }
+    if (oj) {
+        a = a + c[sj];
+        if (oi) { a = a + c[si + sj]; w = 0.25; } else w = 0.5;
+    }
+    if (ok) {
+        a = a + c[1];
+        if (oi) a = a + c[si + 1];
+        if (oj) {
+            a = a + c[sj + 1];
+            if (oi) a = a + c[si + sj + 1];
+        }
+        w = w * 0.5;
+    }
+    // all-even case: the reference copies the coarse value; 1.0*a == a
+    return (oi || oj || ok) ? w * a : a;
+}
+
+template <bool CORRECT>
+__global__ __launch_bounds__(256) void k_prolong(View ec, View out, int64_t nj, int64_t nk)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBX + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.y * kBY + threadIdx.y;
+    const int64_t i = blockIdx.z;
+    if (k > nk - 2 || j > nj - 2) return;
+    double *o = out.p + out.at(i, j, k);
+    if (i == 0 || j == 0 || k == 0) {
+        if (!CORRECT) o[0] = 0;  // phi - 0 == phi: nothing to do when correcting
+        return;
+    }
+    const double v = interp(ec, i, j, k);
+    if (CORRECT) o[0] = o[0] - v;
+    else o[0] = v;
+}
+
+__global__ __launch_bounds__(256) void k_correct(double *__restrict__ phi,
+                                                 const double *__restrict__ eps, int64_t count)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < count; p += stride)
+        phi[p] = phi[p] - eps[p];
+}
+
+inline dim3 grid_for(int64_t nk, int64_t nj, int64_t ni)
+{
+    return dim3((unsigned)((nk + kBX - 1) / kBX), (unsigned)((nj + kBY - 1) / kBY), (unsigned)ni);
+}
+
+}  // namespace
+
+int64_t residual_partials(const int64_t n[3])
+{
+    dim3 g = grid_for(n[2], n[1], n[0]);
+    return (int64_t)g.x * g.y * g.z;
+}
+
+static int sumsq_blocks(int64_t count)
+{
+    int64_t b = (count + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+int64_t sumsq_partials(int64_t count) { return sumsq_blocks(count); }
+
+void div_eps0(hipStream_t s, View v)
+{
+    hipLaunchKernelGGL(k_div_eps0, grid_for(v.d[2], v.d[1], v.d[0]), dim3(kBX, kBY), 0, s, v);
+}
+
+void smooth_colour(hipStream_t s, View u, View rhs, const int64_t n[3], Coef c, double omega,
+                   int colour)
+{
+    if (n[0] < 3 || n[1] < 3 || n[2] < 3) return;
+    const int64_t half = (n[2] - 2 + 1) / 2;  // k positions of one colour in a row, at most
+    hipLaunchKernelGGL(k_smooth_colour, grid_for(half, n[1] - 2, n[0] - 2), dim3(kBX, kBY), 0, s, u,
+                       rhs, n[1], n[2], c, omega, colour);
+}
+
+void residual(hipStream_t s, View phi, View b, View R, Coef c, double *partials)
+{
+    hipLaunchKernelGGL(k_residual, grid_for(phi.d[2], phi.d[1], phi.d[0]), dim3(kBX, kBY), 0, s, phi,
+                       b, R, c, partials);
+}
+
+void sum_partials(hipStream_t s, const double *partials, int64_t count, double *out)
+{
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, partials, count, out);
+}
+
+void sumsq(hipStream_t s, const double *x, int64_t count, double *partials)
+{
+    hipLaunchKernelGGL(k_sumsq, dim3(sumsq_blocks(count)), dim3(256), 0, s, x, count, partials);
+}
+
+void restrict27(hipStream_t s, View Rf, View Rc)
+{
+    hipLaunchKernelGGL(k_restrict27, grid_for(Rc.d[2], Rc.d[1], Rc.d[0]), dim3(kBX, kBY), 0, s, Rf,
+                       Rc);
+}
+
+void prolong(hipStream_t s, View ec, View ef, const int64_t n[3])
+{
+    hipLaunchKernelGGL(k_prolong<false>, grid_for(n[2] - 1, n[1] - 1, n[0] - 1), dim3(kBX, kBY), 0, s,
+                       ec, ef, n[1], n[2]);
+}
+
+void prolong_correct(hipStream_t s, View ec, View phi, const int64_t n[3])
+{
+    hipLaunchKernelGGL(k_prolong<true>, grid_for(n[2] - 1, n[1] - 1, n[0] - 1), dim3(kBX, kBY), 0, s,
+                       ec, phi, n[1], n[2]);
+}
+
+void correct(hipStream_t s, double *phi, const double *eps, int64_t count)
+{
+    int64_t b = (count + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(k_correct, dim3((unsigned)b), dim3(256), 0, s, phi, eps, count);
+}
+
+}  // namespace mgk
