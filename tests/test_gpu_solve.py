@@ -1,0 +1,145 @@
+"""Whole-solve parity: the HIP cycle driver against the oracle's red-black twin
+(bit-exact state) and against the oracle's lexicographic solver, which is the
+reference's algorithm (converged phi within 1e-6 relative L2 at the same
+residual tolerance -- exact iterate agreement is impossible, the orderings
+differ)."""
+import numpy as np
+import pytest
+
+from util import assert_bit_equal, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def problem(orc, n):
+    N = (n, n, n)
+    return N, orc.main_extents_dh(N), orc.synthetic_rho(N)
+
+
+@pytest.mark.parametrize("n,depth", [(41, 1), (41, 2), (65, 3), (129, 3), (129, 4), (129, 5)])
+def test_cycles_match_rb_oracle_bit_for_bit(gpu, orc, n, depth):
+    """After k iterations phi, R_l and eps_l equal the oracle's red-black twin."""
+    N, dh, rho = problem(orc, n)
+    k = 3
+    phi = np.zeros(N)
+    s = orc.Solver(N, dh, depth)
+    ok, cyc, l2, hist = s.solve(phi, rho, k, 0.0, rb=True)
+    with gpu.Handle(N, dh, depth) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        got_l2 = [h.vcycles(1) for _ in range(k)]
+        assert_bit_equal(h.get_phi(), phi, "phi")
+        for l in range(depth + 1):
+            assert_bit_equal(h.level_array("R", l), s.R(l), f"R_{l}")
+        for l in range(1, depth + 1):
+            assert_bit_equal(h.level_array("eps", l), s.eps(l), f"eps_{l}")
+    assert got_l2 == pytest.approx(list(hist), rel=1e-12)
+
+
+@pytest.mark.parametrize("n,depth", [(41, 2), (129, 3)])
+def test_converged_phi_matches_reference_algorithm(gpu, orc, n, depth):
+    N, dh, rho = problem(orc, n)
+    tol = 1e-6
+    phi_ref = np.zeros(N)
+    ok_ref, cyc_ref, l2_ref, _ = orc.Solver(N, dh, depth).solve(phi_ref, rho, 10000, tol)
+    phi_rb = np.zeros(N)
+    ok_rb, cyc_rb, l2_rb, _ = orc.Solver(N, dh, depth).solve(phi_rb, rho, 10000, tol, rb=True)
+    assert ok_ref and ok_rb
+    with gpu.Handle(N, dh, depth) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        ok, cyc, l2 = h.solve(10000, tol)
+        phi = h.get_phi()
+    assert ok and l2 < tol
+    assert cyc == cyc_rb                      # same stopping iteration as the CPU twin
+    assert_bit_equal(phi, phi_rb, "phi vs red-black oracle")
+    assert rel_l2(phi, phi_ref) <= 1e-6       # vs the reference's lexicographic solve
+    assert l2 == pytest.approx(l2_rb, rel=1e-10)
+
+
+def test_solve_stops_before_correction_like_the_reference(gpu, orc):
+    """The returned phi is the one whose residual passed: recomputing the residual
+    of the returned phi reproduces the reported norm."""
+    N, dh, rho = problem(orc, 65)
+    with gpu.Handle(N, dh, 3) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        ok, cyc, l2 = h.solve(10000, 1e-4)
+        phi = h.get_phi()
+    assert ok
+    R, s = gpu.op_residual(phi, rho, dh)
+    assert np.sqrt(s / phi.size) == pytest.approx(l2, rel=1e-12)
+    assert np.sqrt(s / phi.size) < 1e-4
+
+
+def test_not_converged_is_reported_not_raised(gpu, orc):
+    N, dh, rho = problem(orc, 41)
+    with gpu.Handle(N, dh, 2) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        ok, cyc, l2 = h.solve(2, 1e-12)
+    assert not ok and cyc == 2 and l2 > 1.0
+
+
+def test_warm_start_state_persists_between_solves(gpu, orc):
+    """eps_l are never re-zeroed (reference members): two solve(1) calls equal one solve(2)."""
+    N, dh, rho = problem(orc, 41)
+    with gpu.Handle(N, dh, 2) as a, gpu.Handle(N, dh, 2) as b:
+        for h in (a, b):
+            h.set_rho(rho)
+            h.set_phi(np.zeros(N))
+        a.solve(1, 0.0)
+        a.solve(1, 0.0)
+        b.solve(2, 0.0)
+        assert_bit_equal(a.get_phi(), b.get_phi(), "phi")
+        a.reset_state()
+        assert not a.level_array("eps", 2).any()
+
+
+def test_zero_rho_converges_in_one_check(gpu, orc):
+    """The reference driver's first solve() runs on rho == 0 (cpp/Main.cpp:124)."""
+    N = (41, 41, 41)
+    dh = orc.main_extents_dh(N)
+    with gpu.Handle(N, dh, 2) as h:
+        h.set_rho(np.zeros(N))
+        h.set_phi(np.zeros(N))
+        ok, cyc, l2 = h.solve(10000, 1e-4)
+        assert ok and cyc == 1 and l2 == 0.0
+        assert not h.get_phi().any()
+
+
+def test_non_cubic_grid(gpu, orc):
+    N = (33, 41, 65)
+    dh = (0.01, 0.02, 0.005)
+    rho = orc.synthetic_rho(N)
+    phi = np.zeros(N)
+    s = orc.Solver(N, dh, 2)
+    s.solve(phi, rho, 4, 0.0, rb=True)
+    with gpu.Handle(N, dh, 2) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        h.vcycles(4)
+        assert_bit_equal(h.get_phi(), phi, "phi non-cubic")
+
+
+def test_state_errors(gpu):
+    with gpu.Handle((41, 41, 41), (0.01,) * 3, 2) as h:
+        with pytest.raises(gpu.MgError):
+            h.solve(1, 1e-4)  # no rho/phi yet
+    with pytest.raises(gpu.MgError):
+        gpu.Handle((41, 41, 41), (0.01,) * 3, 5)  # 41 >> 5 == 1 node: too deep
+
+
+def test_headline_size_first_cycles(gpu, orc):
+    """513^3 V5: two iterations bit-identical to the oracle's red-black twin."""
+    N, dh, rho = problem(orc, 513)
+    phi = np.zeros(N)
+    s = orc.Solver(N, dh, 5)
+    ok, cyc, l2, hist = s.solve(phi, rho, 2, 0.0, rb=True)
+    with gpu.Handle(N, dh, 5) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        got = [h.vcycles(1), h.vcycles(1)]
+        got_phi = h.get_phi()
+    assert_bit_equal(got_phi, phi, "phi 513^3")
+    assert got == pytest.approx(list(hist), rel=1e-12)
