@@ -85,6 +85,7 @@ struct Level {
     int nu;
     View R;         // dims n
     View eps;       // dims n+1 (l >= 1); unused on l == 0
+    View eps_alt;   // ping-pong twin of eps for the out-of-place fused sweep
 };
 
 }  // namespace
@@ -94,6 +95,7 @@ struct mg_handle {
     int L;
     Level lv[MG_MAX_LEVELS];
     View phi, b;            // fine potential and rho/EPS_0
+    View phi_alt;           // ping-pong twin of phi for the out-of-place fused sweep
     double *partials = nullptr;
     int64_t n_partials = 0;
     double *d_sum = nullptr;    // device scalar: sum of R_h^2
@@ -104,7 +106,7 @@ struct mg_handle {
     double last_ms = 0;
     // profiling
     bool profiling = false;
-    struct Rec { int kind; hipEvent_t a, b; double bytes; };
+    struct Rec { int kind; hipEvent_t a, b; double bytes; int launches; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> ev_pool;
     mg_timers timers;
@@ -118,6 +120,7 @@ struct Prof {
     mg_handle *h;
     int kind;
     double bytes;
+    int launches = 1;  // kernels launched inside this scope
     hipEvent_t a = nullptr, b = nullptr;
     Prof(mg_handle *h_, int kind_, double bytes_) : h(h_), kind(kind_), bytes(bytes_)
     {
@@ -130,7 +133,7 @@ struct Prof {
     {
         if (!h->profiling) return;
         hipEventRecord(b, h->stream);
-        h->recs.push_back({kind, a, b, bytes});
+        h->recs.push_back({kind, a, b, bytes, launches});
     }
     hipEvent_t take()
     {
@@ -153,7 +156,7 @@ void drain_profile(mg_handle *h)
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             h->timers.ms[r.kind] += ms;
-            h->timers.launches[r.kind] += 1;
+            h->timers.launches[r.kind] += (uint64_t)r.launches;
             h->timers.bytes[r.kind] += r.bytes;
         }
         h->ev_pool.push_back(r.a);
@@ -168,11 +171,10 @@ void enqueue_smooth_residual(mg_handle *h)
 {
     Level &f = h->lv[0];
     const double N = (double)count3(f.n);
-    for (int s = 0; s < f.nu; s++)
-        for (int colour = 0; colour < 2; colour++) {
-            Prof p(h, MG_T_SMOOTH_FINE, 16.0 * N);
-            mgk::smooth_colour(h->stream, h->phi, h->b, f.n, f.c, h->cfg.omega, colour);
-        }
+    {
+        Prof p(h, MG_T_SMOOTH_FINE, 32.0 * N * f.nu);
+        p.launches = mgk::smooth_rb(h->stream, &h->phi, &h->phi_alt, h->b, f.n, f.c, h->cfg.omega, f.nu);
+    }
     {
         Prof p(h, MG_T_RESIDUAL, 24.0 * N);
         mgk::residual(h->stream, h->phi, h->b, f.R, f.c, h->partials);
@@ -198,11 +200,10 @@ void enqueue_coarse_correction(mg_handle *h)
             Prof p(h, MG_T_PROLONG, 9.0 * (double)count3(v.n));
             mgk::prolong(h->stream, h->lv[l + 1].eps, v.eps, v.n);
         }
-        for (int s = 0; s < v.nu; s++)
-            for (int colour = 0; colour < 2; colour++) {
-                Prof p(h, MG_T_SMOOTH_COARSE, 16.0 * (double)count3(v.n));
-                mgk::smooth_colour(h->stream, v.eps, v.R, v.n, v.c, h->cfg.omega, colour);
-            }
+        {
+            Prof p(h, MG_T_SMOOTH_COARSE, 32.0 * (double)count3(v.n) * v.nu);
+            p.launches = mgk::smooth_rb(h->stream, &v.eps, &v.eps_alt, v.R, v.n, v.c, h->cfg.omega, v.nu);
+        }
     }
     {
         Prof p(h, MG_T_PROLONG_CORRECT, 17.0 * (double)count3(h->lv[0].n));
@@ -335,9 +336,13 @@ int mg_create(const mg_config *cfg, mg_handle **out)
         v.c = level_coef(cfg->dh, l);
         v.nu = cfg->nu[l];
         CREATE_TRY(alloc_view(&v.R, v.n));
-        if (l >= 1) CREATE_TRY(alloc_view(&v.eps, en));
+        if (l >= 1) {
+            CREATE_TRY(alloc_view(&v.eps, en));
+            CREATE_TRY(alloc_view(&v.eps_alt, en));
+        }
     }
     CREATE_TRY(alloc_view(&h->phi, h->lv[0].n));
+    CREATE_TRY(alloc_view(&h->phi_alt, h->lv[0].n));
     CREATE_TRY(alloc_view(&h->b, h->lv[0].n));
     h->n_partials = mgk::residual_partials(h->lv[0].n);
     CREATE_TRY(hip_try(hipMalloc((void **)&h->partials, (size_t)h->n_partials * sizeof(double)), "hipMalloc(partials)"));
@@ -359,8 +364,10 @@ int mg_destroy(mg_handle *h)
     for (int l = 0; l < MG_MAX_LEVELS; l++) {
         if (h->lv[l].R.p) hipFree(h->lv[l].R.p);
         if (h->lv[l].eps.p) hipFree(h->lv[l].eps.p);
+        if (h->lv[l].eps_alt.p) hipFree(h->lv[l].eps_alt.p);
     }
     if (h->phi.p) hipFree(h->phi.p);
+    if (h->phi_alt.p) hipFree(h->phi_alt.p);
     if (h->b.p) hipFree(h->b.p);
     if (h->partials) hipFree(h->partials);
     if (h->d_sum) hipFree(h->d_sum);
@@ -685,8 +692,9 @@ int mg_op_smooth_rb(int device, const int64_t n[3], const int64_t u_dims[3], con
         if (u_dims[a] < n[a] || rhs_dims[a] < n[a]) return fail(MG_ERR_INVALID, "mg_op_smooth_rb: array dims smaller than n");
     TRY(select_device(device));
     Scratch sc;
-    View vu, vr;
+    View vu, valt, vr;
     TRY(sc.view(&vu, u_dims, u));
+    TRY(sc.view(&valt, u_dims, nullptr));
     TRY(sc.view(&vr, rhs_dims, rhs));
     if (rhs_is_rho) mgk::div_eps0(nullptr, vr);
     Coef k;
@@ -694,8 +702,7 @@ int mg_op_smooth_rb(int device, const int64_t n[3], const int64_t u_dims[3], con
     k.cy = c[1];
     k.cz = c[2];
     k.d = 2 * c[0] + 2 * c[1] + 2 * c[2];
-    for (int s = 0; s < sweeps; s++)
-        for (int colour = 0; colour < 2; colour++) mgk::smooth_colour(nullptr, vu, vr, n, k, omega, colour);
+    mgk::smooth_rb(nullptr, &vu, &valt, vr, n, k, omega, sweeps);
     HIP_TRY(hipGetLastError());
     return sc.download(vu, u);
 }

@@ -33,6 +33,15 @@ void div_eps0(hipStream_t s, View v);
 // One colour of red-black GS-SOR on u over 1..n-2 per axis (n = level size).
 void smooth_colour(hipStream_t s, View u, View rhs, const int64_t n[3], Coef c,
                    double omega, int colour);
+// One full red-black sweep (both colours) in a single pass, out of place:
+// u_out = sweep(u_in); elements outside 1..n-2 are copied through.
+void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c,
+                    double omega);
+// `sweeps` red-black sweeps on *u.  May ping-pong between *u and *alt (same dims);
+// on return *u is the view holding the result and *alt the other buffer.
+// Returns the number of kernels launched.
+int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c,
+               double omega, int sweeps);
 // R = A*phi - b inside, R = phi on faces; block partial sums of R^2 -> partials.
 void residual(hipStream_t s, View phi, View b, View R, Coef c, double *partials);
 // out[0] = sum of partials[0..count) in a fixed order.

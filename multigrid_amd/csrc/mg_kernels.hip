@@ -8,6 +8,9 @@
 // march inside the kernel) covers i.
 #include "mg_kernels.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace mgk {
 
 namespace {
@@ -229,6 +232,42 @@ void smooth_colour(hipStream_t s, View u, View rhs, const int64_t n[3], Coef c, 
     const int64_t half = (n[2] - 2 + 1) / 2;  // k positions of one colour in a row, at most
     hipLaunchKernelGGL(k_smooth_colour, grid_for(half, n[1] - 2, n[0] - 2), dim3(kBX, kBY), 0, s, u,
                        rhs, n[1], n[2], c, omega, colour);
+}
+
+// Kernel choice for the smoother: the fused single-pass sweep pays once the level
+// no longer fits the caches; tiny levels are launch-latency bound either way.
+// MG_SMOOTH=simple|fused overrides (for A/B measurements).
+static bool use_fused_sweep(const View &u)
+{
+    static const int forced = [] {
+        const char *e = getenv("MG_SMOOTH");
+        if (!e) return 0;
+        if (!strcmp(e, "simple")) return 1;
+        if (!strcmp(e, "fused")) return 2;
+        return 0;
+    }();
+    if (forced == 1) return false;
+    if (forced == 2) return true;
+    return u.d[0] >= 64 && u.d[1] >= 64 && u.d[2] >= 64;
+}
+
+int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c,
+              double omega, int sweeps)
+{
+    if (n[0] < 3 || n[1] < 3 || n[2] < 3) return 0;
+    const bool fused = alt && alt->p && use_fused_sweep(*u);
+    for (int sw = 0; sw < sweeps; sw++) {
+        if (fused) {
+            sweep_rb_fused(s, *u, *alt, rhs, n, c, omega);
+            View t = *u;
+            *u = *alt;
+            *alt = t;
+        } else {
+            smooth_colour(s, *u, rhs, n, c, omega, 0);
+            smooth_colour(s, *u, rhs, n, c, omega, 1);
+        }
+    }
+    return fused ? sweeps : 2 * sweeps;
 }
 
 void residual(hipStream_t s, View phi, View b, View R, Coef c, double *partials)
