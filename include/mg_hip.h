@@ -53,7 +53,8 @@ typedef struct mg_handle mg_handle;
  *           (cpp/PotentialSolver.cpp:2422-2425, :2629-2634, :2922-2929,
  *            :3298-3307, :3759-3770)
  *   omega   SOR factor, 1.4 in the reference (cpp/PotentialSolver.cpp:3786)
- *   device  HIP device ordinal */
+ *   device  HIP device ordinal
+ *   flags   0, or MG_FLAG_KEEP_FINE_RESIDUAL */
 typedef struct mg_config {
     int64_t n[3];
     double dh[3];
@@ -61,8 +62,15 @@ typedef struct mg_config {
     int32_t nu[MG_MAX_LEVELS];
     double omega;
     int32_t device;
-    int32_t reserved;
+    int32_t flags;  /* MG_FLAG_* */
 } mg_config;
+
+/* Keep the fine-grid residual R_h in device memory, as the reference does
+ * (cpp/PotentialSolver.h:188).  Nothing but the norm and the restriction reads
+ * R_h, so by default it is produced and consumed on chip and never stored;
+ * with this flag the cycle uses separate residual and restriction kernels and
+ * mg_get_level_array(h, 0, 0, ...) works.  Results are bit-identical either way. */
+#define MG_FLAG_KEEP_FINE_RESIDUAL 1
 
 /* Accumulated device time per operator, measured with HIP events on the
  * handle's stream while profiling is on (mg_set_profiling).  Index with
@@ -129,9 +137,13 @@ int mg_vcycles(mg_handle *h, unsigned count, double *L2);
 int mg_reset_state(mg_handle *h);
 
 /* Copy a level's work array to the host, for state comparison with the
- * reference members.  which: 0 = R_l (dims n>>l), 1 = eps_l (dims (n>>l)+1 for
- * l >= 1; eps_0 does not exist on the device, the fine prolongation is fused
- * with the correction).  dims_out receives the array dims. */
+ * reference members.  which: 0 = R_l (dims n>>l; R_0 only with
+ * MG_FLAG_KEEP_FINE_RESIDUAL), 1 = eps_l (dims (n>>l)+1 for l >= 1; eps_0 does not
+ * exist on the device, the fine prolongation is fused with the correction).
+ * dims_out receives the array dims.  Note: R_1 is refreshed together with the
+ * residual norm, i.e. also in the iteration that converges (the reference
+ * restricts only after the termination test); no later computation reads the
+ * difference. */
 int mg_get_level_array(mg_handle *h, int which, int level, double *out_flat,
                        int64_t dims_out[3]);
 
@@ -151,6 +163,13 @@ int mg_last_call_ms(mg_handle *h, double *ms);
 int mg_op_residual(int device, const int64_t n[3], const double dh[3],
                    const double *phi, const double *rho, double *R_out,
                    double *sumsq);
+/* The fused form the solver uses by default: R_coarse = restrict27(residual)
+ * and *sumsq in one pass (cpp/PotentialSolver.cpp:3792-3839).  R_fine_out may be
+ * NULL (the fine residual is then never stored); R_coarse (dims n>>1) is
+ * read-modify-written like in mg_op_restrict27. */
+int mg_op_residual_restrict(int device, const int64_t n[3], const double dh[3],
+                            const double *phi, const double *rho, double *R_fine_out,
+                            double *R_coarse, double *sumsq);
 /* 27-point full weighting, injection where an index is 0
  * (cpp/PotentialSolver.cpp:3822-3839).  R_coarse has dims n_fine>>1 and is
  * read-modify-written: entries the loop does not reach keep their values. */

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -103,6 +104,7 @@ struct mg_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bool have_rho = false, have_phi = false;
+    bool fused_residual = true;  // R_0 never stored (default); false with MG_FLAG_KEEP_FINE_RESIDUAL
     double last_ms = 0;
     // profiling
     bool profiling = false;
@@ -175,13 +177,22 @@ void enqueue_smooth_residual(mg_handle *h)
         Prof p(h, MG_T_SMOOTH_FINE, 32.0 * N * f.nu);
         p.launches = mgk::smooth_rb(h->stream, &h->phi, &h->phi_alt, h->b, f.n, f.c, h->cfg.omega, f.nu);
     }
-    {
+    int64_t np;
+    if (h->fused_residual) {
+        // residual, sum of squares and restriction to level 1 in one pass; R_0 stays on chip
+        Prof p(h, MG_T_RESIDUAL, 17.0 * N);
+        View none = f.R;
+        none.p = nullptr;
+        mgk::residual_restrict(h->stream, h->phi, h->b, none, h->lv[1].R, f.c, h->partials);
+        np = mgk::residual_restrict_partials(f.n);
+    } else {
         Prof p(h, MG_T_RESIDUAL, 24.0 * N);
         mgk::residual(h->stream, h->phi, h->b, f.R, f.c, h->partials);
+        np = mgk::residual_partials(f.n);
     }
     {
-        Prof p(h, MG_T_NORM, 8.0 * (double)h->n_partials);
-        mgk::sum_partials(h->stream, h->partials, h->n_partials, h->d_sum);
+        Prof p(h, MG_T_NORM, 8.0 * (double)np);
+        mgk::sum_partials(h->stream, h->partials, np, h->d_sum);
     }
     hipMemcpyAsync(h->h_sum, h->d_sum, sizeof(double), hipMemcpyDeviceToHost, h->stream);
 }
@@ -190,7 +201,7 @@ void enqueue_smooth_residual(mg_handle *h)
 void enqueue_coarse_correction(mg_handle *h)
 {
     const int L = h->L;
-    for (int l = 0; l < L; l++) {
+    for (int l = h->fused_residual ? 1 : 0; l < L; l++) {
         Prof p(h, MG_T_RESTRICT, 9.0 * (double)count3(h->lv[l].n));
         mgk::restrict27(h->stream, h->lv[l].R, h->lv[l + 1].R);
     }
@@ -309,6 +320,8 @@ int mg_create(const mg_config *cfg, mg_handle **out)
     if (!h) return fail(MG_ERR_NOMEM, "host allocation failed");
     h->cfg = *cfg;
     h->L = L;
+    h->fused_residual = !(cfg->flags & MG_FLAG_KEEP_FINE_RESIDUAL);
+    if (getenv("MG_KEEP_RF")) h->fused_residual = false;  // A/B measurements
     memset(&h->timers, 0, sizeof(h->timers));
     memset(h->lv, 0, sizeof(h->lv));
 #define CREATE_TRY(expr)          \
@@ -335,7 +348,8 @@ int mg_create(const mg_config *cfg, mg_handle **out)
         }
         v.c = level_coef(cfg->dh, l);
         v.nu = cfg->nu[l];
-        CREATE_TRY(alloc_view(&v.R, v.n));
+        if (l >= 1 || !h->fused_residual) CREATE_TRY(alloc_view(&v.R, v.n));
+        else v.R = make_view(nullptr, v.n);
         if (l >= 1) {
             CREATE_TRY(alloc_view(&v.eps, en));
             CREATE_TRY(alloc_view(&v.eps_alt, en));
@@ -344,7 +358,8 @@ int mg_create(const mg_config *cfg, mg_handle **out)
     CREATE_TRY(alloc_view(&h->phi, h->lv[0].n));
     CREATE_TRY(alloc_view(&h->phi_alt, h->lv[0].n));
     CREATE_TRY(alloc_view(&h->b, h->lv[0].n));
-    h->n_partials = mgk::residual_partials(h->lv[0].n);
+    h->n_partials = h->fused_residual ? mgk::residual_restrict_partials(h->lv[0].n)
+                                      : mgk::residual_partials(h->lv[0].n);
     CREATE_TRY(hip_try(hipMalloc((void **)&h->partials, (size_t)h->n_partials * sizeof(double)), "hipMalloc(partials)"));
     CREATE_TRY(hip_try(hipMalloc((void **)&h->d_sum, sizeof(double)), "hipMalloc(sum)"));
     CREATE_TRY(hip_try(hipHostMalloc((void **)&h->h_sum, sizeof(double), hipHostMallocDefault), "hipHostMalloc"));
@@ -468,7 +483,7 @@ int mg_reset_state(mg_handle *h)
     if (!h) return fail(MG_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->cfg.device));
     for (int l = 0; l <= h->L; l++) {
-        HIP_TRY(hipMemsetAsync(h->lv[l].R.p, 0, (size_t)h->lv[l].R.elems() * sizeof(double), h->stream));
+        if (h->lv[l].R.p) HIP_TRY(hipMemsetAsync(h->lv[l].R.p, 0, (size_t)h->lv[l].R.elems() * sizeof(double), h->stream));
         if (l >= 1) HIP_TRY(hipMemsetAsync(h->lv[l].eps.p, 0, (size_t)h->lv[l].eps.elems() * sizeof(double), h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -481,6 +496,8 @@ int mg_get_level_array(mg_handle *h, int which, int level, double *out_flat, int
     if (level < 0 || level > h->L) return fail(MG_ERR_INVALID, "level %d out of range", level);
     if (which != 0 && which != 1) return fail(MG_ERR_INVALID, "which must be 0 (R) or 1 (eps)");
     if (which == 1 && level == 0) return fail(MG_ERR_INVALID, "eps_0 is not materialised on the device");
+    if (which == 0 && level == 0 && h->fused_residual)
+        return fail(MG_ERR_STATE, "R_0 is kept only with MG_FLAG_KEEP_FINE_RESIDUAL");
     HIP_TRY(hipSetDevice(h->cfg.device));
     View src = which == 0 ? h->lv[level].R : h->lv[level].eps;
     int rc = d2h(out_flat, src, h->stream);
@@ -611,6 +628,34 @@ int mg_op_residual(int device, const int64_t n[3], const double dh[3], const dou
     TRY(reduce_to_host(partials, np, &s));
     if (sumsq) *sumsq = s;
     return sc.download(vR, R_out);
+}
+
+int mg_op_residual_restrict(int device, const int64_t n[3], const double dh[3], const double *phi,
+                            const double *rho, double *R_fine_out, double *R_coarse, double *sumsq)
+{
+    if (!dh || !phi || !rho || !R_coarse) return fail(MG_ERR_INVALID, "null argument");
+    TRY(check_dims(n, "mg_op_residual_restrict", 3));
+    TRY(select_device(device));
+    int64_t nc[3];
+    for (int a = 0; a < 3; a++) nc[a] = n[a] >> 1;
+    Scratch sc;
+    View vphi, vb, vR, vc;
+    TRY(sc.view(&vphi, n, phi));
+    TRY(sc.view(&vb, n, rho));
+    mgk::div_eps0(nullptr, vb);
+    if (R_fine_out) TRY(sc.view(&vR, n, nullptr));
+    else vR = make_view(nullptr, n);
+    TRY(sc.view(&vc, nc, R_coarse));
+    double *partials = nullptr;
+    const int64_t np = mgk::residual_restrict_partials(n);
+    TRY(sc.flat(&partials, np, nullptr));
+    mgk::residual_restrict(nullptr, vphi, vb, vR, vc, level_coef(dh, 0), partials);
+    HIP_TRY(hipGetLastError());
+    double s = 0;
+    TRY(reduce_to_host(partials, np, &s));
+    if (sumsq) *sumsq = s;
+    if (R_fine_out) TRY(sc.download(vR, R_fine_out));
+    return sc.download(vc, R_coarse);
 }
 
 int mg_op_restrict27(int device, const int64_t n_fine[3], const double *R_fine, double *R_coarse)

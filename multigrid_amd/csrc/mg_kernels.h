@@ -44,6 +44,12 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
                double omega, int sweeps);
 // R = A*phi - b inside, R = phi on faces; block partial sums of R^2 -> partials.
 void residual(hipStream_t s, View phi, View b, View R, Coef c, double *partials);
+// Fused residual + sum of squares + restriction to the next level: Rc =
+// restrict27(residual(phi, b)); per-workgroup partial sums of squares of the fine
+// residual go to partials[0..residual_restrict_partials(n)).  The fine residual
+// itself is written only when Rf.p is non-null.
+int64_t residual_restrict_partials(const int64_t n[3]);
+void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, Coef c, double *partials);
 // out[0] = sum of partials[0..count) in a fixed order.
 void sum_partials(hipStream_t s, const double *partials, int64_t count, double *out);
 // partial sums of x^2 over a flat array

@@ -17,6 +17,7 @@ namespace {
 
 constexpr int kBX = 64;  // lanes along k
 constexpr int kBY = 4;   // rows along j per workgroup
+constexpr int kLdsSmoothMaxBytes = 128 * 1024;  // u + rhs of a level handled by k_smooth_lds
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -67,6 +68,53 @@ __global__ __launch_bounds__(256) void k_smooth_colour(View u, View rhs, int64_t
                       c.cz * (p[-1] + p[1])) / c.d;
     const double u0 = p[0];
     p[0] = u0 + omega * (g - u0);
+}
+
+// All sweeps of a small level inside one workgroup: u and rhs live in LDS, the
+// two colours are separated by workgroup barriers instead of kernel boundaries.
+// Used for the coarsest grid, whose 50 sweeps would otherwise be 100 launches
+// of a few thousand points each.
+__global__ __launch_bounds__(1024) void k_smooth_lds(View u, View rhs, int nI, int nJ, int nK,
+                                                     Coef c, double omega, int sweeps)
+{
+    extern __shared__ __align__(16) double sm[];
+    const int uI = (int)u.d[0], uJ = (int)u.d[1], uK = (int)u.d[2];
+    const int rJ = (int)rhs.d[1], rK = (int)rhs.d[2];
+    double *su = sm;                 // dense copy of u, strides (uJ*uK, uK, 1)
+    double *sr = sm + uI * uJ * uK;  // dense copy of rhs over 0..nI-1 planes
+    const int tid = threadIdx.x;
+    for (int p = tid; p < uI * uJ * uK; p += 1024) {
+        const int k = p % uK, j = (p / uK) % uJ, i = p / (uK * uJ);
+        su[p] = u.p[u.at(i, j, k)];
+    }
+    for (int p = tid; p < nI * rJ * rK; p += 1024) {
+        const int k = p % rK, j = (p / rK) % rJ, i = p / (rK * rJ);
+        sr[p] = rhs.p[rhs.at(i, j, k)];
+    }
+    __syncthreads();
+    const int half = (nK - 1) / 2;  // colour positions per row, at most
+    const int rows = (nI - 2) * (nJ - 2);
+    const int si = uJ * uK, sj = uK;
+    for (int s = 0; s < sweeps; s++)
+        for (int colour = 0; colour < 2; colour++) {
+            for (int idx = tid; idx < rows * half; idx += 1024) {
+                const int m = idx % half, t = idx / half;
+                const int j = 1 + t % (nJ - 2), i = 1 + t / (nJ - 2);
+                const int k = 1 + ((i + j + 1 + colour) & 1) + 2 * m;
+                if (k <= nK - 2) {
+                    double *p = su + i * si + j * sj + k;
+                    const double g = (sr[(i * rJ + j) * rK + k] + c.cx * (p[-si] + p[si]) +
+                                      c.cy * (p[-sj] + p[sj]) + c.cz * (p[-1] + p[1])) / c.d;
+                    const double u0 = p[0];
+                    p[0] = u0 + omega * (g - u0);
+                }
+            }
+            __syncthreads();
+        }
+    for (int p = tid; p < uI * uJ * uK; p += 1024) {
+        const int k = p % uK, j = (p / uK) % uJ, i = p / (uK * uJ);
+        u.p[u.at(i, j, k)] = su[p];
+    }
 }
 
 // Residual (reference cpp/PotentialSolver.cpp:3792-3805) with the workgroup's
@@ -145,50 +193,67 @@ __global__ __launch_bounds__(256) void k_restrict27(View Rf, View Rc)
     Rc.p[Rc.at(I, J, K)] = v;
 }
 
-// Trilinear interpolant of ec at fine node (i,j,k), none of the indices 0
-// (reference cpp/PotentialSolver.cpp:4176-4205).  The eight parity cases share
-// their leading partial sums, so they fold into: a = sum over the K plane in the
-// reference's order, then (k odd) the K+1 plane's terms appended in that order.
-__device__ __forceinline__ double interp(const View &ec, int64_t i, int64_t j, int64_t k)
-{
-    const double *c = ec.p + ec.at(i >> 1, j >> 1, k >> 1);
-    const int64_t si = ec.si, sj = ec.sj;
-    const bool oi = i & 1, oj = j & 1, ok = k & 1;
-    double a = c[0];
-    double w = 1.0;
-    if (oi) { a = a + c[si]; w = 0.5; }
-    if (oj) {
-        a = a + c[sj];
-        if (oi) { a = a + c[si + sj]; w = 0.25; } else w = 0.5;
-    }
-    if (ok) {
-        a = a + c[1];
-        if (oi) a = a + c[si + 1];
-        if (oj) {
-            a = a + c[sj + 1];
-            if (oi) a = a + c[si + sj + 1];
-        }
-        w = w * 0.5;
-    }
-    // all-even case: the reference copies the coarse value; 1.0*a == a
-    return (oi || oj || ok) ? w * a : a;
-}
+// Prolongation by coarse cell: a thread takes the eight coarse corner values of
+// cell (I,J,K) and produces the eight fine points (2I+di, 2J+dj, 2K+dk), as four
+// 16-byte pairs along k.  The eight parity cases of the reference
+// (cpp/PotentialSolver.cpp:4176-4205) are written out with their shared leading
+// partial sums, in the reference's association order.
+// CORRECT: out = out - v (out is phi); otherwise out = v (out is eps of the finer level).
+struct alignas(16) dpair { double x, y; };
 
 template <bool CORRECT>
-__global__ __launch_bounds__(256) void k_prolong(View ec, View out, int64_t nj, int64_t nk)
+__global__ __launch_bounds__(256) void k_prolong(View ec, View out, int64_t nI, int64_t nJ, int64_t nK)
 {
-    const int64_t k = (int64_t)blockIdx.x * kBX + threadIdx.x;
-    const int64_t j = (int64_t)blockIdx.y * kBY + threadIdx.y;
-    const int64_t i = blockIdx.z;
-    if (k > nk - 2 || j > nj - 2) return;
-    double *o = out.p + out.at(i, j, k);
-    if (i == 0 || j == 0 || k == 0) {
-        if (!CORRECT) o[0] = 0;  // phi - 0 == phi: nothing to do when correcting
-        return;
+    const int64_t K = (int64_t)blockIdx.x * kBX + threadIdx.x;
+    const int64_t J = (int64_t)blockIdx.y * kBY + threadIdx.y;
+    const int64_t I = blockIdx.z;
+    // fine points 0..n-2 per axis are written; cell K covers k = 2K, 2K+1
+    if (2 * K > nK - 2 || 2 * J > nJ - 2) return;
+    const double *c = ec.p + ec.at(I, J, K);
+    const int64_t si = ec.si, sj = ec.sj;
+    const double c000 = c[0], c100 = c[si], c010 = c[sj], c110 = c[si + sj];
+    const double c001 = c[1], c101 = c[si + 1], c011 = c[sj + 1], c111 = c[si + sj + 1];
+    const double s100 = c000 + c100;          // (1,0,0) and prefix of (1,1,*), (1,0,1)
+    const double s010 = c000 + c010;          // (0,1,0) and prefix of (0,1,1)
+    const double s110 = (s100 + c010) + c110; // (1,1,0) and prefix of (1,1,1)
+    double v[2][2][2];                        // [di][dj][dk]
+    v[0][0][0] = c000;
+    v[1][0][0] = 0.5 * s100;
+    v[0][1][0] = 0.5 * s010;
+    v[0][0][1] = 0.5 * (c000 + c001);
+    v[1][1][0] = 0.25 * s110;
+    v[1][0][1] = 0.25 * ((s100 + c001) + c101);
+    v[0][1][1] = 0.25 * ((s010 + c001) + c011);
+    v[1][1][1] = 0.125 * ((((s110 + c001) + c101) + c011) + c111);
+    const bool k1 = 2 * K + 1 <= nK - 2;  // second point of the pair is inside the loop range
+#pragma unroll
+    for (int di = 0; di < 2; di++) {
+        const int64_t i = 2 * I + di;
+        if (i > nI - 2) continue;
+#pragma unroll
+        for (int dj = 0; dj < 2; dj++) {
+            const int64_t j = 2 * J + dj;
+            if (j > nJ - 2) continue;
+            const bool zero = i == 0 || j == 0;  // reference: eps = 0 where any index is 0
+            double vx = (zero || K == 0) ? 0.0 : v[di][dj][0];
+            double vy = zero ? 0.0 : v[di][dj][1];
+            dpair *o = reinterpret_cast<dpair *>(out.p + out.at(i, j, 2 * K));
+            if (CORRECT) {
+                if (zero) continue;  // phi - 0 == phi
+                dpair t = *o;
+                if (K != 0) t.x = t.x - vx;
+                if (k1) t.y = t.y - vy;
+                *o = t;
+            } else if (k1) {
+                dpair t;
+                t.x = vx;
+                t.y = vy;
+                *o = t;
+            } else {
+                out.p[out.at(i, j, 2 * K)] = vx;
+            }
+        }
     }
-    const double v = interp(ec, i, j, k);
-    if (CORRECT) o[0] = o[0] - v;
-    else o[0] = v;
 }
 
 __global__ __launch_bounds__(256) void k_correct(double *__restrict__ phi,
@@ -255,6 +320,19 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
               double omega, int sweeps)
 {
     if (n[0] < 3 || n[1] < 3 || n[2] < 3) return 0;
+    // small enough for one workgroup's LDS: all sweeps in a single launch
+    const size_t lds_bytes = sizeof(double) * (size_t)(u->d[0] * u->d[1] * u->d[2] + n[0] * rhs.d[1] * rhs.d[2]);
+    static const bool lds_ok = [] {
+        const char *e = getenv("MG_SMOOTH_LDS");
+        if (e && !strcmp(e, "0")) return false;
+        return hipFuncSetAttribute((const void *)k_smooth_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kLdsSmoothMaxBytes) == hipSuccess;
+    }();
+    if (lds_ok && lds_bytes <= (size_t)kLdsSmoothMaxBytes && sweeps > 0) {
+        hipLaunchKernelGGL(k_smooth_lds, dim3(1), dim3(1024), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
+                           (int)n[2], c, omega, sweeps);
+        return 1;
+    }
     const bool fused = alt && alt->p && use_fused_sweep(*u);
     for (int sw = 0; sw < sweeps; sw++) {
         if (fused) {
@@ -294,14 +372,14 @@ void restrict27(hipStream_t s, View Rf, View Rc)
 
 void prolong(hipStream_t s, View ec, View ef, const int64_t n[3])
 {
-    hipLaunchKernelGGL(k_prolong<false>, grid_for(n[2] - 1, n[1] - 1, n[0] - 1), dim3(kBX, kBY), 0, s,
-                       ec, ef, n[1], n[2]);
+    hipLaunchKernelGGL(k_prolong<false>, grid_for(n[2] / 2, n[1] / 2, n[0] / 2), dim3(kBX, kBY), 0, s, ec,
+                       ef, n[0], n[1], n[2]);
 }
 
 void prolong_correct(hipStream_t s, View ec, View phi, const int64_t n[3])
 {
-    hipLaunchKernelGGL(k_prolong<true>, grid_for(n[2] - 1, n[1] - 1, n[0] - 1), dim3(kBX, kBY), 0, s,
-                       ec, phi, n[1], n[2]);
+    hipLaunchKernelGGL(k_prolong<true>, grid_for(n[2] / 2, n[1] / 2, n[0] / 2), dim3(kBX, kBY), 0, s, ec,
+                       phi, n[0], n[1], n[2]);
 }
 
 void correct(hipStream_t s, double *phi, const double *eps, int64_t count)

@@ -1,0 +1,231 @@
+// Fused fine-grid residual + sum of squares + full-weighting restriction.
+//
+// Unfused, the cycle writes R_h (8 B/pt), reads it back for the norm and again for
+// the restriction.  R_h has no other consumer, so here it never reaches memory: a
+// workgroup marches a (j,k) window along i, computes the residual plane by plane
+// into a three-plane LDS ring, adds the squares of the points it owns to its
+// partial sum, and after every odd plane emits one plane of the restricted
+// residual from the ring.  Traffic: phi 8 + rhs 8 + R_2h 1 = 17 bytes per fine point.
+//
+// Ownership: a lane owns PAIRS of adjacent k in Q vertically adjacent rows, so
+// the j+-1 neighbours of a point are in the lane's own registers (except at the
+// ends of its row block: two extra pair loads, cache hits), the k+-1 neighbours
+// come from the adjacent lane by wave shuffle, and i+-1 are the same columns one
+// plane earlier/later, also registers.  LDS holds only residual planes.
+//
+// Arithmetic is the reference's, term by term (cpp/PotentialSolver.cpp:3792-3839):
+// the 27 restriction terms are added left to right with the first index fastest.
+#include "mg_kernels.h"
+
+#include <cstdlib>
+
+namespace mgk {
+
+namespace {
+
+struct alignas(16) d2 { double x, y; };
+
+__device__ __forceinline__ double wave_sum64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// WJ x 2*WKP window of fine points; residual valid on the window minus one ring;
+// owned (norm, restriction centres) = window minus two rings.
+template <int WJ, int WKP, int D, bool STORE_RF>
+__global__ __launch_bounds__(256) void k_residual_restrict(View phi, View b, View Rf, View Rc, Coef c,
+                                                           double *__restrict__ partials, int CI,
+                                                           int nchunks, int tiles_k)
+{
+    static_assert(WKP == 32, "row shuffles assume 32 lanes per row");
+    constexpr int WK = 2 * WKP;
+    constexpr int G = 256 / WKP;   // row blocks per workgroup
+    constexpr int Q = WJ / G;      // adjacent rows per lane
+    constexpr int TJ = WJ - 4, TK = WK - 4;   // owned fine rows / columns (even)
+    constexpr int TJC = TJ / 2, TKC = TK / 2; // coarse outputs per tile and coarse plane
+    __shared__ double ring[3][WJ][WK];
+    __shared__ double red[4];
+
+    const int tid = threadIdx.x;
+    const int m = tid % WKP, g = tid / WKP;
+    const int chunk = blockIdx.x % nchunks;
+    const int tile = blockIdx.x / nchunks;
+    const int tk = tile % tiles_k, tj = tile / tiles_k;
+    const int j0 = tj * TJ - 2, k0 = tk * TK - 2;
+    const int nI = (int)phi.d[0], nJ = (int)phi.d[1], nK = (int)phi.d[2];
+    const int cI = (int)Rc.d[0], cJ = (int)Rc.d[1], cK = (int)Rc.d[2];
+    const int ia = chunk * CI;
+    const int ib = min(ia + CI, nI);
+    double acc = 0.0;
+    if (ia < ib) {
+        const int kk = k0 + 2 * m;
+        const int kkc = min(max(kk, 0), (nK - 1) & ~1);
+        // row index rq = -1..Q: the lane's Q rows plus the row above and below its block
+        auto row_of = [&](int rq) { return g * Q + rq; };
+        auto load = [&](const View &v, int i, int rq) -> d2 {
+            const int j = min(max(j0 + row_of(rq), 0), nJ - 1);
+            const int ic = min(max(i, 0), nI - 1);
+            return *reinterpret_cast<const d2 *>(v.p + v.at(ic, j, kkc));
+        };
+
+        // planes p-1 (own rows only), p, p+1 and D planes in flight; index rq+1
+        d2 um1[Q], u0[Q + 2], up1[Q + 2], uf[D][Q + 2], b0[Q], bp1[Q], bf[D][Q];
+#pragma unroll
+        for (int q = 0; q < Q + 2; q++) {
+            u0[q] = load(phi, ia - 1, q - 1);
+            up1[q] = load(phi, ia, q - 1);
+#pragma unroll
+            for (int d = 0; d + 1 < D; d++) uf[d][q] = load(phi, ia + 1 + d, q - 1);
+        }
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            um1[q] = load(phi, ia - 2, q);
+            b0[q] = load(b, ia - 1, q);
+            bp1[q] = load(b, ia, q);
+#pragma unroll
+            for (int d = 0; d + 1 < D; d++) bf[d][q] = load(b, ia + 1 + d, q);
+        }
+
+        for (int p = ia - 1; p < ib; p++) {
+            const int pl = min(p + 1 + D, ib);
+#pragma unroll
+            for (int q = 0; q < Q + 2; q++) uf[D - 1][q] = load(phi, pl, q - 1);
+#pragma unroll
+            for (int q = 0; q < Q; q++) bf[D - 1][q] = load(b, pl, q);
+
+            if (p >= 0) {
+                double(*S)[WK] = ring[p % 3];
+                const bool iface = p == 0 || p == nI - 1;
+                const bool iown = p >= ia;
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const int r = row_of(q);
+                    const int j = j0 + r;
+                    const d2 u = u0[q + 1];
+                    const double left = __shfl_up(u.y, 1, WKP);
+                    const double right = __shfl_down(u.x, 1, WKP);
+                    d2 rr;
+                    rr.x = u.x * c.d - b0[q].x - c.cx * (um1[q].x + up1[q + 1].x) -
+                           c.cy * (u0[q].x + u0[q + 2].x) - c.cz * (left + u.y);
+                    rr.y = u.y * c.d - b0[q].y - c.cx * (um1[q].y + up1[q + 1].y) -
+                           c.cy * (u0[q].y + u0[q + 2].y) - c.cz * (u.x + right);
+                    const bool jface = j == 0 || j == nJ - 1;
+                    if (iface || jface || kk == 0 || kk == nK - 1) rr.x = u.x - 0;
+                    if (iface || jface || kk + 1 == 0 || kk + 1 == nK - 1) rr.y = u.y - 0;
+                    *reinterpret_cast<d2 *>(&S[r][2 * m]) = rr;
+                    const bool own = iown && r >= 2 && r <= WJ - 3 && m >= 1 && m <= WKP - 2 && j < nJ;
+                    if (own && kk < nK) {
+                        acc += rr.x * rr.x;
+                        if (STORE_RF) Rf.p[Rf.at(p, j, kk)] = rr.x;
+                    }
+                    if (own && kk + 1 < nK) {
+                        acc += rr.y * rr.y;
+                        if (STORE_RF) Rf.p[Rf.at(p, j, kk + 1)] = rr.y;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- one plane of R_2h from residual planes p-2, p-1, p ---------
+            if ((p & 1) && p >= ia + 1) {
+                const int I = (p - 1) >> 1;
+                if (I < cI) {
+                    double(*A)[WK] = ring[(p - 2 + 3) % 3];  // plane 2I-1
+                    double(*B)[WK] = ring[(p - 1) % 3];      // plane 2I
+                    double(*C)[WK] = ring[p % 3];            // plane 2I+1
+                    for (int t = tid; t < TJC * TKC; t += 256) {
+                        const int Jl = t / TKC, Kl = t % TKC;
+                        const int J = tj * TJC + Jl, K = tk * TKC + Kl;
+                        if (J < cJ && K < cK) {
+                            const int r = 2 * Jl + 2, cc = 2 * Kl + 2;
+                            double v;
+                            if (I == 0 || J == 0 || K == 0) {
+                                v = B[r][cc];
+                            } else {
+#define F(di, dj, dk) ((di) < 0 ? A : (di) == 0 ? B : C)[r + (dj)][cc + (dk)]
+                                v = F(-1, -1, -1) + 2 * F(0, -1, -1) + F(1, -1, -1) +
+                                    2 * F(-1, 0, -1) + 4 * F(0, 0, -1) + 2 * F(1, 0, -1) +
+                                    F(-1, 1, -1) + 2 * F(0, 1, -1) + F(1, 1, -1) +
+                                    2 * F(-1, -1, 0) + 4 * F(0, -1, 0) + 2 * F(1, -1, 0) +
+                                    4 * F(-1, 0, 0) + 8 * F(0, 0, 0) + 4 * F(1, 0, 0) +
+                                    2 * F(-1, 1, 0) + 4 * F(0, 1, 0) + 2 * F(1, 1, 0) +
+                                    F(-1, -1, 1) + 2 * F(0, -1, 1) + F(1, -1, 1) +
+                                    2 * F(-1, 0, 1) + 4 * F(0, 0, 1) + 2 * F(1, 0, 1) +
+                                    F(-1, 1, 1) + 2 * F(0, 1, 1) + F(1, 1, 1);
+#undef F
+                                v = v / 64.0;
+                            }
+                            Rc.p[Rc.at(I, J, K)] = v;
+                        }
+                    }
+                }
+                __syncthreads();  // ring slot (p-2)%3 is overwritten by plane p+1 next
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                um1[q] = u0[q + 1];
+                b0[q] = bp1[q];
+                bp1[q] = bf[0][q];
+#pragma unroll
+                for (int d = 0; d + 1 < D; d++) bf[d][q] = bf[d + 1][q];
+            }
+#pragma unroll
+            for (int q = 0; q < Q + 2; q++) {
+                u0[q] = up1[q];
+                up1[q] = uf[0][q];
+#pragma unroll
+                for (int d = 0; d + 1 < D; d++) uf[d][q] = uf[d + 1][q];
+            }
+        }
+    }
+    // workgroup partial sum, fixed order
+    acc = wave_sum64(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+struct Geometry {
+    int tiles_j, tiles_k, nchunks, CI;
+    unsigned grid;
+};
+
+Geometry geometry(const int64_t n[3])
+{
+    constexpr int TJ = 28, TK = 60;
+    Geometry g;
+    g.tiles_j = (int)((n[1] + TJ - 1) / TJ);
+    g.tiles_k = (int)((n[2] + TK - 1) / TK);
+    int nchunks = 8;
+    while ((int64_t)nchunks * g.tiles_j * g.tiles_k < 1024 && n[0] / (nchunks * 2) >= 8) nchunks *= 2;
+    if (n[0] < 16) nchunks = 1;
+    static const int want = [] { const char *e = getenv("MG_RR_CHUNKS"); return e ? atoi(e) : 0; }();
+    if (want > 0) nchunks = want;
+    int CI = (int)((n[0] + nchunks - 1) / nchunks);
+    CI += CI & 1;  // chunks start on even planes: a coarse plane's three fine planes stay together
+    g.nchunks = nchunks;
+    g.CI = CI;
+    g.grid = (unsigned)(nchunks * g.tiles_j * g.tiles_k);
+    return g;
+}
+
+}  // namespace
+
+int64_t residual_restrict_partials(const int64_t n[3]) { return geometry(n).grid; }
+
+// R_c = restrict27(residual(phi, b)), partials[0..residual_restrict_partials) = per-workgroup
+// sums of squares of the fine residual.  Rf.p may be null (the fine residual is then
+// never written).
+void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, Coef c, double *partials)
+{
+    const Geometry g = geometry(phi.d);
+    if (Rf.p)
+        hipLaunchKernelGGL((k_residual_restrict<32, 32, 2, true>), dim3(g.grid), dim3(256), 0, s, phi, b,
+                           Rf, Rc, c, partials, g.CI, g.nchunks, g.tiles_k);
+    else
+        hipLaunchKernelGGL((k_residual_restrict<32, 32, 2, false>), dim3(g.grid), dim3(256), 0, s, phi, b,
+                           Rf, Rc, c, partials, g.CI, g.nchunks, g.tiles_k);
+}
+
+}  // namespace mgk

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmg_hip.so")
 
 MG_MAX_LEVELS = 12
 MG_ABI_VERSION = 1
+MG_FLAG_KEEP_FINE_RESIDUAL = 1
 
 TIMER_KINDS = ("smooth_fine", "residual", "restrict", "smooth_coarse", "prolong",
                "prolong_correct", "norm")
@@ -26,7 +27,7 @@ _dp = C.POINTER(C.c_double)
 class MgConfig(C.Structure):
     _fields_ = [("n", C.c_int64 * 3), ("dh", C.c_double * 3), ("depth", C.c_int32),
                 ("nu", C.c_int32 * MG_MAX_LEVELS), ("omega", C.c_double),
-                ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("device", C.c_int32), ("flags", C.c_int32)]
 
 
 class MgTimers(C.Structure):
@@ -63,6 +64,7 @@ SYMBOLS = {
     "mg_reset_timers": (C.c_int, [_H]),
     "mg_last_call_ms": (C.c_int, [_H, _dp]),
     "mg_op_residual": (C.c_int, [C.c_int, _i64x3, _f64x3, _dp, _dp, _dp, _dp]),
+    "mg_op_residual_restrict": (C.c_int, [C.c_int, _i64x3, _f64x3, _dp, _dp, _dp, _dp, _dp]),
     "mg_op_restrict27": (C.c_int, [C.c_int, _i64x3, _dp, _dp]),
     "mg_op_prolong": (C.c_int, [C.c_int, _i64x3, _i64x3, _dp, _dp]),
     "mg_op_correct": (C.c_int, [C.c_int, C.c_int64, _dp, _dp]),
@@ -121,7 +123,7 @@ def default_config(n, dh, depth, device=0):
 class Handle:
     """Owns one mg_handle (one reference MultiGridSolverVn object's worth of state)."""
 
-    def __init__(self, n, dh, depth, nu=None, omega=None, device=0):
+    def __init__(self, n, dh, depth, nu=None, omega=None, device=0, flags=0):
         self.n = tuple(int(a) for a in n)
         self.depth = depth
         cfg = default_config(self.n, dh, depth, device)
@@ -132,6 +134,7 @@ class Handle:
                 cfg.nu[l] = v
         if omega is not None:
             cfg.omega = omega
+        cfg.flags = flags
         self.cfg = cfg
         self._h = _H()
         _check(load().mg_create(C.byref(cfg), C.byref(self._h)))
@@ -218,6 +221,19 @@ def op_residual(phi, rho, dh, device=0):
     s = C.c_double(0)
     _check(load().mg_op_residual(device, _i64x3(*phi.shape), _f64x3(*dh), pp, pr, _out(R), C.byref(s)))
     return R, s.value
+
+
+def op_residual_restrict(phi, rho, dh, Rc=None, want_fine=False, device=0):
+    """Returns (R_fine or None, R_coarse, sum of squares)."""
+    phi, pp = _in(phi)
+    rho, pr = _in(rho)
+    if Rc is None:
+        Rc = np.zeros(tuple(s >> 1 for s in phi.shape))
+    Rf = np.empty_like(phi) if want_fine else None
+    s = C.c_double(0)
+    _check(load().mg_op_residual_restrict(device, _i64x3(*phi.shape), _f64x3(*dh), pp, pr,
+                                          _out(Rf) if want_fine else None, _out(Rc), C.byref(s)))
+    return Rf, Rc, s.value
 
 
 def op_restrict27(Rf, Rc=None, device=0):

@@ -1,7 +1,10 @@
 """Per-operator parity of the HIP kernels, called through the C ABI, against the
 CPU oracle on the same inputs.  The bar is bit equality (which implies the
-<= 1e-12 relative-per-element requirement); only the sum of squares, whose
-summation order differs from the sequential loop, is compared to 1e-13 relative.
+<= 1e-12 relative-per-element requirement).  Only the sum of squares differs by
+construction: the GPU adds in a tree order, the reference sequentially, and the
+sequential sum of ~1e6 positive terms itself carries ~1e-13 relative rounding
+error.  It is therefore checked against the exactly rounded sum (math.fsum) to
+1e-14 and against the oracle's sequential sum to 1e-11.
 
 The oracle itself is pinned only by recorded reference residual histories
 (see tests/test_oracle_known_answers.py): per-operator parity with the reference
@@ -9,7 +12,15 @@ is therefore "unpinned" beyond what those histories imply."""
 import numpy as np
 import pytest
 
+import math
+
 from util import assert_bit_equal, phi_like, rho_like, rng
+
+
+def assert_sumsq(got, R, seq):
+    exact = math.fsum((R.ravel() * R.ravel()).tolist())
+    assert got == pytest.approx(exact, rel=1e-14)
+    assert got == pytest.approx(seq, rel=1e-11)
 
 pytestmark = pytest.mark.gpu
 
@@ -29,7 +40,7 @@ def test_residual(gpu, orc, shape):
     want_R, want_sum = orc.residual(phi, rho, orc.coeffs(dh_for(shape), 0))
     got_R, got_sum = gpu.op_residual(phi, rho, dh_for(shape))
     assert_bit_equal(got_R, want_R, "residual")
-    assert got_sum == pytest.approx(want_sum, rel=1e-13)
+    assert_sumsq(got_sum, want_R, want_sum)
 
 
 def test_residual_near_convergence(gpu, orc):
@@ -42,7 +53,23 @@ def test_residual_near_convergence(gpu, orc):
     want_R, want_sum = orc.residual(phi, rho, orc.coeffs(dh, 0))
     got_R, got_sum = gpu.op_residual(phi, rho, dh)
     assert_bit_equal(got_R, want_R, "residual near convergence")
-    assert got_sum == pytest.approx(want_sum, rel=1e-13)
+    assert_sumsq(got_sum, want_R, want_sum)
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(28, 60, 60), (29, 61, 61), (57, 121, 30)], ids=str)
+@pytest.mark.parametrize("want_fine", [False, True], ids=["rf_on_chip", "rf_stored"])
+def test_fused_residual_restrict(gpu, orc, shape, want_fine):
+    """The fused kernel equals restrict27(residual(phi, rho)) bit for bit."""
+    g = rng(11)
+    phi, rho = phi_like(shape, g), rho_like(shape, g)
+    Rc0 = phi_like(tuple(s >> 1 for s in shape), g)
+    want_R, want_sum = orc.residual(phi, rho, orc.coeffs(dh_for(shape), 0))
+    want_Rc = orc.restrict27(want_R, Rc0.copy())
+    got_R, got_Rc, got_sum = gpu.op_residual_restrict(phi, rho, dh_for(shape), Rc0.copy(), want_fine)
+    assert_bit_equal(got_Rc, want_Rc, "restricted residual")
+    if want_fine:
+        assert_bit_equal(got_R, want_R, "fine residual")
+    assert_sumsq(got_sum, want_R, want_sum)
 
 
 @pytest.mark.parametrize("shape", [s for s in SHAPES if min(s) >= 4] + [(2, 2, 2), (3, 2, 5)], ids=str)
@@ -118,7 +145,7 @@ def test_smooth_rb_coarse_form(gpu, orc, n, sweeps):
 @pytest.mark.parametrize("count", [1, 7, 4096, 41 ** 3, 129 ** 3])
 def test_sumsq(gpu, orc, count):
     x = phi_like((count,), rng(8))
-    assert gpu.op_sumsq(x) == pytest.approx(orc.sumsq(x), rel=1e-13)
+    assert_sumsq(gpu.op_sumsq(x), x, orc.sumsq(x))
 
 
 def test_sumsq_is_deterministic(gpu):

@@ -16,20 +16,26 @@ def problem(orc, n):
     return N, orc.main_extents_dh(N), orc.synthetic_rho(N)
 
 
-@pytest.mark.parametrize("n,depth", [(41, 1), (41, 2), (65, 3), (129, 3), (129, 4), (129, 5)])
-def test_cycles_match_rb_oracle_bit_for_bit(gpu, orc, n, depth):
-    """After k iterations phi, R_l and eps_l equal the oracle's red-black twin."""
+@pytest.mark.parametrize("keep_rf", [False, True], ids=["default", "keep_fine_residual"])
+@pytest.mark.parametrize("n,depth", [(41, 1), (41, 2), (65, 3), (129, 3), (129, 4), (129, 5), (257, 5)])
+def test_cycles_match_rb_oracle_bit_for_bit(gpu, orc, n, depth, keep_rf):
+    """After k iterations phi, R_l and eps_l equal the oracle's red-black twin.
+    By default R_0 is never stored (fused residual+restriction); with
+    MG_FLAG_KEEP_FINE_RESIDUAL the unfused kernels run and R_0 is compared too."""
     N, dh, rho = problem(orc, n)
     k = 3
     phi = np.zeros(N)
     s = orc.Solver(N, dh, depth)
     ok, cyc, l2, hist = s.solve(phi, rho, k, 0.0, rb=True)
-    with gpu.Handle(N, dh, depth) as h:
+    with gpu.Handle(N, dh, depth, flags=gpu.MG_FLAG_KEEP_FINE_RESIDUAL if keep_rf else 0) as h:
         h.set_rho(rho)
         h.set_phi(np.zeros(N))
         got_l2 = [h.vcycles(1) for _ in range(k)]
         assert_bit_equal(h.get_phi(), phi, "phi")
-        for l in range(depth + 1):
+        if not keep_rf:
+            with pytest.raises(gpu.MgError):
+                h.level_array("R", 0)
+        for l in range(0 if keep_rf else 1, depth + 1):
             assert_bit_equal(h.level_array("R", l), s.R(l), f"R_{l}")
         for l in range(1, depth + 1):
             assert_bit_equal(h.level_array("eps", l), s.eps(l), f"eps_{l}")
