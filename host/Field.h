@@ -1,0 +1,79 @@
+// Mesh-node containers with the reference's access surface (cpp/Field.h:55-218 of
+// jcoady/MultiGrid): a 3-D field indexed f[i][j][k] through T***, k contiguous,
+// zero-filled at construction, public const ni/nj/nk.  Written from scratch for the
+// HIP host adapter; only what the multigrid path and its driver touch is provided.
+//
+// Unlike the reference (one heap block per (i,j) row) the node data is ONE block in
+// [i][j][k] order with two pointer tables on top, so flat() can hand the whole field
+// to the device library without a packing pass.  Code that only uses f[i][j][k],
+// f(i,j,k), clear() and ni/nj/nk cannot tell the difference.
+#ifndef MG_HOST_FIELD_H
+#define MG_HOST_FIELD_H
+
+#include <cstddef>
+#include <ostream>
+#include <vector>
+
+template <typename T>
+struct vec3 {
+    vec3() : d{T(), T(), T()} {}
+    vec3(T a, T b, T c) : d{a, b, c} {}
+    T &operator[](int a) { return d[a]; }
+    T operator()(int a) const { return d[a]; }
+    vec3 &operator=(double s) { d[0] = d[1] = d[2] = T(s); return *this; }
+
+protected:
+    T d[3];
+};
+template <typename T> vec3<T> operator+(const vec3<T> &a, const vec3<T> &b) { return {a(0) + b(0), a(1) + b(1), a(2) + b(2)}; }
+template <typename T> vec3<T> operator-(const vec3<T> &a, const vec3<T> &b) { return {a(0) - b(0), a(1) - b(1), a(2) - b(2)}; }
+template <typename T> vec3<T> operator*(T s, const vec3<T> &a) { return {s * a(0), s * a(1), s * a(2)}; }
+template <typename T> std::ostream &operator<<(std::ostream &o, const vec3<T> &v) { return o << v(0) << " " << v(1) << " " << v(2); }
+
+using double3 = vec3<double>;
+using int3 = vec3<int>;
+
+template <typename T>
+class Field_ {
+public:
+    Field_(int ni_, int nj_, int nk_)
+        : ni(ni_), nj(nj_), nk(nk_), cells(std::size_t(ni_) * nj_ * nk_), rows(std::size_t(ni_) * nj_),
+          planes(ni_)
+    {
+        for (int i = 0; i < ni; i++) {
+            planes[i] = rows.data() + std::size_t(i) * nj;
+            for (int j = 0; j < nj; j++) planes[i][j] = cells.data() + (std::size_t(i) * nj + j) * nk;
+        }
+        data = planes.data();
+    }
+    Field_(const Field_ &o) : Field_(o.ni, o.nj, o.nk) { cells = o.cells; }
+    Field_ &operator=(const Field_ &) = delete;
+
+    T **operator[](int i) { return data[i]; }                          // f[i][j][k]
+    T operator()(int i, int j, int k) const { return data[i][j][k]; }  // read-only access
+    void operator=(double s) { for (T &c : cells) c = T(s); }
+    void clear() { (*this) = 0; }
+    Field_ &operator+=(const Field_ &o) { for (std::size_t p = 0; p < cells.size(); p++) cells[p] += o.cells[p]; return *this; }
+    Field_ &operator*=(double s) { for (T &c : cells) c *= s; return *this; }
+    // logical node number with i fastest (cpp/Field.h:161); not the memory order
+    int U(int i, int j, int k) const { return k * ni * nj + j * ni + i; }
+
+    // the node data in memory order ((i*nj)+j)*nk+k
+    T *flat() { return cells.data(); }
+    const T *flat() const { return cells.data(); }
+    std::size_t size() const { return cells.size(); }
+
+    const int ni, nj, nk;
+
+protected:
+    std::vector<T> cells;
+    std::vector<T *> rows;
+    std::vector<T **> planes;
+    T ***data;
+};
+
+using Field = Field_<double>;
+using FieldI = Field_<int>;
+using Field3 = Field_<double3>;
+
+#endif

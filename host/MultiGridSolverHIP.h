@@ -1,0 +1,60 @@
+// HIP-backed multigrid solvers behind the reference's PotentialSolver interface.
+//
+//   MultiGridSolverHIP             depth-generic V-cycle solver on an MI355X through libmg_hip
+//   hip::MultiGridSolver, V2..V5   same constructor signature (World&, int max_it, double tol) as
+//                                  the reference classes of those names
+//                                  (cpp/PotentialSolver.h:171-272), with their sweep schedules
+//
+// solve() contract (unchanged from the reference): reads world.phi (initial guess and
+// Dirichlet face values), world.rho, world.getDh(); overwrites world.phi; returns true iff
+// the residual norm fell below `tol` within `max_it` iterations, otherwise prints
+// "GS failed to converge, L2=<value>" to stderr and returns false
+// (cpp/PotentialSolver.cpp:4246-4247).  Solver-private work fields persist between calls.
+// There is no CPU fallback: if the device library reports an error, solve() throws
+// std::runtime_error with the library's message.
+//
+// This header and MultiGridSolverHIP.cpp use only the public surface of World and Field
+// (phi, rho, getDh(), ni/nj/nk, f[i][j] row pointers), so they also compile against the
+// reference's own World.h / Field.h / PotentialSolver.h.
+#ifndef MG_HOST_MULTIGRID_SOLVER_HIP_H
+#define MG_HOST_MULTIGRID_SOLVER_HIP_H
+
+#include <vector>
+
+#include "PotentialSolver.h"
+
+struct mg_handle;
+
+class MultiGridSolverHIP : public PotentialSolver {
+public:
+    // depth = number of coarse grids (1..5 = the reference's MultiGridSolver, V2, .. V5)
+    MultiGridSolverHIP(World &world, int max_it, double tol, int depth, int device = 0);
+    ~MultiGridSolverHIP() override;
+    MultiGridSolverHIP(const MultiGridSolverHIP &) = delete;
+    MultiGridSolverHIP &operator=(const MultiGridSolverHIP &) = delete;
+
+    bool solve() override;
+
+    // diagnostics of the last solve()
+    unsigned cycles() const { return last_cycles; }
+    double residualNorm() const { return last_l2; }
+    double deviceMilliseconds() const;
+
+protected:
+    unsigned max_solver_it;  // same names as the reference members (cpp/PotentialSolver.h:85-86)
+    double tolerance;
+    mg_handle *handle = nullptr;
+    std::vector<double> stage;  // dense copy of a field whose rows are not contiguous
+    unsigned last_cycles = 0;
+    double last_l2 = 0;
+};
+
+namespace hip {
+struct MultiGridSolver : MultiGridSolverHIP { MultiGridSolver(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 1) {} };
+struct MultiGridSolverV2 : MultiGridSolverHIP { MultiGridSolverV2(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 2) {} };
+struct MultiGridSolverV3 : MultiGridSolverHIP { MultiGridSolverV3(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 3) {} };
+struct MultiGridSolverV4 : MultiGridSolverHIP { MultiGridSolverV4(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 4) {} };
+struct MultiGridSolverV5 : MultiGridSolverHIP { MultiGridSolverV5(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 5) {} };
+}  // namespace hip
+
+#endif

@@ -1,0 +1,21 @@
+// The plug-in boundary of the reference (cpp/PotentialSolver.h:49-68): an abstract solver
+// bound to a World, used through a base pointer (cpp/Main.cpp:59,124,157).
+#ifndef MG_HOST_POTENTIAL_SOLVER_H
+#define MG_HOST_POTENTIAL_SOLVER_H
+
+#include "World.h"
+
+class PotentialSolver {
+public:
+    explicit PotentialSolver(World &w) : world(w) {}
+    virtual ~PotentialSolver() {}
+    virtual bool solve() = 0;
+    // E = -grad(phi), central differences inside, one-sided 3-point on the faces
+    // (cpp/PotentialSolver.cpp:418-458)
+    void computeEF();
+
+protected:
+    World &world;
+};
+
+#endif

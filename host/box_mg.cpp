@@ -1,0 +1,68 @@
+// Minimal driver in the shape of the reference's main loop around the solver
+// (cpp/Main.cpp:29-39, :88-100, :124-126, :155-166): cubic mesh of argv[1] nodes, the reference
+// box, 0 V walls, a multigrid solver chosen by depth, solve() timed with the same clock.
+// The particle species that produce rho in the reference are replaced by the deterministic
+// synthetic charge density used by this repository's benchmarks.
+//
+//   box_mg [n=41] [depth=2] [tol=1e-4] [--dump file]   (--dump writes phi as raw fp64, [i][j][k])
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <iostream>
+
+#include "MultiGridSolverHIP.h"
+
+int main(int argc, char **argv)
+{
+    int n = 41, depth = 2;
+    double tol = 1e-4;
+    const char *dump = nullptr;
+    int pos = 0;
+    for (int a = 1; a < argc; a++) {
+        if (!strcmp(argv[a], "--dump") && a + 1 < argc) dump = argv[++a];
+        else if (pos == 0) { n = atoi(argv[a]); pos++; }
+        else if (pos == 1) { depth = atoi(argv[a]); pos++; }
+        else if (pos == 2) { tol = atof(argv[a]); pos++; }
+    }
+    std::cout << "Using mesh size : " << n << "x" << n << "x" << n << std::endl;
+    try {
+        World world(n, n, n);
+        world.setExtents({-0.2, -0.2, -0.1}, {0.2, 0.2, 0.3});
+        world.setBoundaries();
+        const double pi = std::acos(-1.0);
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++)
+                for (int k = 0; k < n; k++) {
+                    const double x = double(i) / (n - 1), y = double(j) / (n - 1), z = double(k) / (n - 1);
+                    world.rho[i][j][k] = Const::EPS_0 * 1000.0 *
+                                         (std::sin(pi * x) * std::sin(pi * y) * std::sin(pi * z) +
+                                          0.5 * std::sin(5 * pi * x) * std::sin(3 * pi * y) * std::sin(7 * pi * z));
+                }
+        MultiGridSolverHIP *mg = new MultiGridSolverHIP(world, 10000, tol, depth);
+        PotentialSolver *solver = mg;  // used through the base pointer, like the reference driver
+        auto t0 = std::chrono::high_resolution_clock::now();
+        const bool ok = solver->solve();
+        auto t1 = std::chrono::high_resolution_clock::now();
+        solver->computeEF();
+        std::chrono::duration<double> dt = t1 - t0;
+        std::cout << "Simulation took " << dt.count() << " secs for solver1 to solve potential" << std::endl;
+        std::cout << "converged=" << ok << " cycles=" << mg->cycles() << " L2=" << mg->residualNorm()
+                  << " device_ms=" << mg->deviceMilliseconds() << std::endl;
+        if (dump) {
+            FILE *f = fopen(dump, "wb");
+            if (!f || fwrite(world.phi.flat(), sizeof(double), world.phi.size(), f) != world.phi.size()) {
+                std::cerr << "cannot write " << dump << std::endl;
+                return 3;
+            }
+            fclose(f);
+        }
+        delete solver;
+        return ok ? 0 : 2;
+    } catch (const std::exception &e) {
+        std::cerr << "box_mg: " << e.what() << std::endl;
+        return 1;
+    }
+}
