@@ -12,6 +12,7 @@
 #include <vector>
 
 using mgk::Coef;
+using mgk::IRange;
 using mgk::View;
 
 namespace {
@@ -68,6 +69,7 @@ View make_view(double *p, const int64_t d[3])
     for (int a = 0; a < 3; a++) v.d[a] = d[a];
     v.sj = mgk::pitch_for(d[2]);
     v.si = v.sj * d[1];
+    v.i0 = 0;
     return v;
 }
 
@@ -175,7 +177,8 @@ void enqueue_smooth_residual(mg_handle *h)
     const double N = (double)count3(f.n);
     {
         Prof p(h, MG_T_SMOOTH_FINE, 32.0 * N * f.nu);
-        p.launches = mgk::smooth_rb(h->stream, &h->phi, &h->phi_alt, h->b, f.n, f.c, h->cfg.omega, f.nu);
+        p.launches = mgk::smooth_rb(h->stream, &h->phi, &h->phi_alt, h->b, f.n, f.c, h->cfg.omega, f.nu,
+                                    IRange{0, f.n[0]});
     }
     int64_t np;
     if (h->fused_residual) {
@@ -183,12 +186,13 @@ void enqueue_smooth_residual(mg_handle *h)
         Prof p(h, MG_T_RESIDUAL, 17.0 * N);
         View none = f.R;
         none.p = nullptr;
-        mgk::residual_restrict(h->stream, h->phi, h->b, none, h->lv[1].R, f.c, h->partials);
-        np = mgk::residual_restrict_partials(f.n);
+        mgk::residual_restrict(h->stream, h->phi, h->b, none, h->lv[1].R, f.n, f.c, h->partials,
+                               IRange{0, f.n[0]});
+        np = mgk::residual_restrict_partials(f.n, IRange{0, f.n[0]});
     } else {
         Prof p(h, MG_T_RESIDUAL, 24.0 * N);
-        mgk::residual(h->stream, h->phi, h->b, f.R, f.c, h->partials);
-        np = mgk::residual_partials(f.n);
+        mgk::residual(h->stream, h->phi, h->b, f.R, f.n, f.c, h->partials, IRange{0, f.n[0]});
+        np = mgk::residual_partials(f.n, IRange{0, f.n[0]});
     }
     {
         Prof p(h, MG_T_NORM, 8.0 * (double)np);
@@ -203,22 +207,23 @@ void enqueue_coarse_correction(mg_handle *h)
     const int L = h->L;
     for (int l = h->fused_residual ? 1 : 0; l < L; l++) {
         Prof p(h, MG_T_RESTRICT, 9.0 * (double)count3(h->lv[l].n));
-        mgk::restrict27(h->stream, h->lv[l].R, h->lv[l + 1].R);
+        mgk::restrict27(h->stream, h->lv[l].R, h->lv[l + 1].R, h->lv[l].n, IRange{0, h->lv[l + 1].n[0]});
     }
     for (int l = L; l >= 1; l--) {
         Level &v = h->lv[l];
         if (l < L) {
             Prof p(h, MG_T_PROLONG, 9.0 * (double)count3(v.n));
-            mgk::prolong(h->stream, h->lv[l + 1].eps, v.eps, v.n);
+            mgk::prolong(h->stream, h->lv[l + 1].eps, v.eps, v.n, IRange{0, v.n[0]});
         }
         {
             Prof p(h, MG_T_SMOOTH_COARSE, 32.0 * (double)count3(v.n) * v.nu);
-            p.launches = mgk::smooth_rb(h->stream, &v.eps, &v.eps_alt, v.R, v.n, v.c, h->cfg.omega, v.nu);
+            p.launches = mgk::smooth_rb(h->stream, &v.eps, &v.eps_alt, v.R, v.n, v.c, h->cfg.omega, v.nu,
+                                        IRange{0, v.eps.d[0]});
         }
     }
     {
         Prof p(h, MG_T_PROLONG_CORRECT, 17.0 * (double)count3(h->lv[0].n));
-        mgk::prolong_correct(h->stream, h->lv[1].eps, h->phi, h->lv[0].n);
+        mgk::prolong_correct(h->stream, h->lv[1].eps, h->phi, h->lv[0].n, IRange{0, h->lv[0].n[0]});
     }
 }
 
@@ -358,8 +363,11 @@ int mg_create(const mg_config *cfg, mg_handle **out)
     CREATE_TRY(alloc_view(&h->phi, h->lv[0].n));
     CREATE_TRY(alloc_view(&h->phi_alt, h->lv[0].n));
     CREATE_TRY(alloc_view(&h->b, h->lv[0].n));
-    h->n_partials = h->fused_residual ? mgk::residual_restrict_partials(h->lv[0].n)
-                                      : mgk::residual_partials(h->lv[0].n);
+    {
+        const IRange all{0, h->lv[0].n[0]};
+        h->n_partials = h->fused_residual ? mgk::residual_restrict_partials(h->lv[0].n, all)
+                                          : mgk::residual_partials(h->lv[0].n, all);
+    }
     CREATE_TRY(hip_try(hipMalloc((void **)&h->partials, (size_t)h->n_partials * sizeof(double)), "hipMalloc(partials)"));
     CREATE_TRY(hip_try(hipMalloc((void **)&h->d_sum, sizeof(double)), "hipMalloc(sum)"));
     CREATE_TRY(hip_try(hipHostMalloc((void **)&h->h_sum, sizeof(double), hipHostMallocDefault), "hipHostMalloc"));
@@ -620,9 +628,10 @@ int mg_op_residual(int device, const int64_t n[3], const double dh[3], const dou
     mgk::div_eps0(nullptr, vb);  // b = rho/EPS_0
     TRY(sc.view(&vR, n, nullptr));
     double *partials = nullptr;
-    const int64_t np = mgk::residual_partials(n);
+    const IRange all{0, n[0]};
+    const int64_t np = mgk::residual_partials(n, all);
     TRY(sc.flat(&partials, np, nullptr));
-    mgk::residual(nullptr, vphi, vb, vR, level_coef(dh, 0), partials);
+    mgk::residual(nullptr, vphi, vb, vR, n, level_coef(dh, 0), partials, all);
     HIP_TRY(hipGetLastError());
     double s = 0;
     TRY(reduce_to_host(partials, np, &s));
@@ -647,9 +656,10 @@ int mg_op_residual_restrict(int device, const int64_t n[3], const double dh[3], 
     else vR = make_view(nullptr, n);
     TRY(sc.view(&vc, nc, R_coarse));
     double *partials = nullptr;
-    const int64_t np = mgk::residual_restrict_partials(n);
+    const IRange all{0, n[0]};
+    const int64_t np = mgk::residual_restrict_partials(n, all);
     TRY(sc.flat(&partials, np, nullptr));
-    mgk::residual_restrict(nullptr, vphi, vb, vR, vc, level_coef(dh, 0), partials);
+    mgk::residual_restrict(nullptr, vphi, vb, vR, vc, n, level_coef(dh, 0), partials, all);
     HIP_TRY(hipGetLastError());
     double s = 0;
     TRY(reduce_to_host(partials, np, &s));
@@ -669,7 +679,7 @@ int mg_op_restrict27(int device, const int64_t n_fine[3], const double *R_fine, 
     View vf, vc;
     TRY(sc.view(&vf, n_fine, R_fine));
     TRY(sc.view(&vc, nc, R_coarse));
-    mgk::restrict27(nullptr, vf, vc);
+    mgk::restrict27(nullptr, vf, vc, n_fine, IRange{0, nc[0]});
     HIP_TRY(hipGetLastError());
     return sc.download(vc, R_coarse);
 }
@@ -689,7 +699,7 @@ int mg_op_prolong(int device, const int64_t n[3], const int64_t fine_dims[3], co
     View vc, vf;
     TRY(sc.view(&vc, cd, eps_coarse));
     TRY(sc.view(&vf, fine_dims, eps_fine));
-    mgk::prolong(nullptr, vc, vf, n);
+    mgk::prolong(nullptr, vc, vf, n, IRange{0, n[0]});
     HIP_TRY(hipGetLastError());
     return sc.download(vf, eps_fine);
 }
@@ -720,7 +730,7 @@ int mg_op_prolong_correct(int device, const int64_t n[3], const double *eps_coar
     View vc, vphi;
     TRY(sc.view(&vc, cd, eps_coarse));
     TRY(sc.view(&vphi, n, phi));
-    mgk::prolong_correct(nullptr, vc, vphi, n);
+    mgk::prolong_correct(nullptr, vc, vphi, n, IRange{0, n[0]});
     HIP_TRY(hipGetLastError());
     return sc.download(vphi, phi);
 }
@@ -747,7 +757,7 @@ int mg_op_smooth_rb(int device, const int64_t n[3], const int64_t u_dims[3], con
     k.cy = c[1];
     k.cz = c[2];
     k.d = 2 * c[0] + 2 * c[1] + 2 * c[2];
-    mgk::smooth_rb(nullptr, &vu, &valt, vr, n, k, omega, sweeps);
+    mgk::smooth_rb(nullptr, &vu, &valt, vr, n, k, omega, sweeps, IRange{0, u_dims[0]});
     HIP_TRY(hipGetLastError());
     return sc.download(vu, u);
 }

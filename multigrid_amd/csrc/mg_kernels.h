@@ -1,5 +1,12 @@
 // Internal launcher interface between the C ABI (mg_api.hip) and the gfx950
-// kernels (mg_kernels.hip).  Not part of the public boundary.
+// kernels (mg_kernels.hip, mg_sweep.hip, mg_resrest.hip).  Not part of the public
+// boundary.
+//
+// Index space: kernels think in GLOBAL node indices of a level.  A View may be a
+// slab of the global array (planes [i0, i0+d[0]) of its first axis, e.g. the
+// planes one GPU owns plus halo planes); at() takes the global i.  Every launcher
+// takes the global plane range [lo, hi) it is to produce, so the same kernels
+// serve the single-GPU case (i0 = 0, range = whole array) and a slab partition.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,57 +15,62 @@ namespace mgk {
 
 constexpr double kEps0 = 8.85418782e-12;  // reference cpp/World.h:14
 
-// A 3-D fp64 array in device memory: element (i,j,k) at p[i*si + j*sj + k].
-// d[] are the logical dims; sj >= d[2] is the (even) row pitch in doubles.
+// A 3-D fp64 array (or a slab of one) in device memory.
 struct View {
     double *p;
-    int64_t d[3];
-    int64_t si, sj;
-    __host__ __device__ int64_t at(int64_t i, int64_t j, int64_t k) const { return i * si + j * sj + k; }
+    int64_t d[3];    // stored planes, rows, columns
+    int64_t si, sj;  // strides in doubles; sj >= d[2] is the (even) row pitch
+    int64_t i0;      // global index of stored plane 0
+    __host__ __device__ int64_t at(int64_t i, int64_t j, int64_t k) const { return (i - i0) * si + j * sj + k; }
+    __host__ __device__ int64_t i_end() const { return i0 + d[0]; }
     int64_t elems() const { return d[0] * si; }  // allocated doubles
 };
+
+struct IRange { int64_t lo, hi; };  // global planes [lo, hi)
 
 // Row pitch used for every device array: rows start 16-byte aligned.
 inline int64_t pitch_for(int64_t nk) { return (nk + 1) & ~int64_t(1); }
 
 struct Coef { double cx, cy, cz, d; };
 
-// Number of partial sums residual()/sumsq() write for a problem of this size.
-int64_t residual_partials(const int64_t n[3]);
-int64_t sumsq_partials(int64_t count);
-
-// v = v / EPS_0 in place: turns an uploaded rho into the right-hand side b.
+// v = v / EPS_0 in place over the whole view: turns an uploaded rho into the rhs b.
 void div_eps0(hipStream_t s, View v);
 
-// One colour of red-black GS-SOR on u over 1..n-2 per axis (n = level size).
-void smooth_colour(hipStream_t s, View u, View rhs, const int64_t n[3], Coef c,
-                   double omega, int colour);
-// One full red-black sweep (both colours) in a single pass, out of place:
-// u_out = sweep(u_in); elements outside 1..n-2 are copied through.
+// One colour of red-black GS-SOR on u, updating planes of r within 1..n-2 (n = level size).
+void smooth_colour(hipStream_t s, View u, View rhs, const int64_t n[3], Coef c, double omega,
+                   int colour, IRange r);
+// One full red-black sweep (both colours) in a single pass, out of place: planes r of
+// u_out = sweep(u_in); points outside 1..n-2 are copied through.  u_in must hold planes
+// [r.lo-2, r.hi+2) as far as they exist in the global array (gI planes).
 void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c,
-                    double omega);
-// `sweeps` red-black sweeps on *u.  May ping-pong between *u and *alt (same dims);
-// on return *u is the view holding the result and *alt the other buffer.
-// Returns the number of kernels launched.
-int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c,
-               double omega, int sweeps);
-// R = A*phi - b inside, R = phi on faces; block partial sums of R^2 -> partials.
-void residual(hipStream_t s, View phi, View b, View R, Coef c, double *partials);
-// Fused residual + sum of squares + restriction to the next level: Rc =
-// restrict27(residual(phi, b)); per-workgroup partial sums of squares of the fine
-// residual go to partials[0..residual_restrict_partials(n)).  The fine residual
-// itself is written only when Rf.p is non-null.
-int64_t residual_restrict_partials(const int64_t n[3]);
-void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, Coef c, double *partials);
+                    double omega, IRange r);
+// `sweeps` red-black sweeps on planes r of *u.  May ping-pong between *u and *alt (same
+// shape); on return *u is the view holding the result.  Returns the kernels launched.
+int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c, double omega,
+              int sweeps, IRange r);
+
+// R = A*phi - b inside, R = phi on the faces of the n-sized level, for planes r; per-workgroup
+// sums of squares go to partials[0..residual_partials(n, r)).
+int64_t residual_partials(const int64_t n[3], IRange r);
+void residual(hipStream_t s, View phi, View b, View R, const int64_t n[3], Coef c, double *partials,
+              IRange r);
+// Fused residual + sum of squares + restriction: coarse planes [r.lo/2, ...) of
+// Rc = restrict27(residual(phi, b)) for fine planes r (r.lo even); the fine residual is
+// written only when Rf.p is non-null.  phi must hold planes [r.lo-2, r.hi+1).
+int64_t residual_restrict_partials(const int64_t n[3], IRange r);
+void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const int64_t n[3], Coef c,
+                       double *partials, IRange r);
 // out[0] = sum of partials[0..count) in a fixed order.
 void sum_partials(hipStream_t s, const double *partials, int64_t count, double *out);
 // partial sums of x^2 over a flat array
+int64_t sumsq_partials(int64_t count);
 void sumsq(hipStream_t s, const double *x, int64_t count, double *partials);
-void restrict27(hipStream_t s, View Rf, View Rc);
-// trilinear prolongation of ec onto ef over 0..n-2 per axis
-void prolong(hipStream_t s, View ec, View ef, const int64_t n[3]);
-// phi -= prolong(ec) over 1..n-2 per axis
-void prolong_correct(hipStream_t s, View ec, View phi, const int64_t n[3]);
+// Coarse planes rc of Rc = restrict27(Rf); nf = size of the fine level.
+void restrict27(hipStream_t s, View Rf, View Rc, const int64_t nf[3], IRange rc);
+// trilinear prolongation of ec onto planes r of ef (within 0..n-2 per axis)
+void prolong(hipStream_t s, View ec, View ef, const int64_t n[3], IRange r);
+// phi -= prolong(ec) on planes r (within 1..n-2 per axis)
+void prolong_correct(hipStream_t s, View ec, View phi, const int64_t n[3], IRange r);
 void correct(hipStream_t s, double *phi, const double *eps, int64_t count);
 
 }  // namespace mgk

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_div_eps0(View v)
 {
     const int64_t k = (int64_t)blockIdx.x * kBX + threadIdx.x;
     const int64_t j = (int64_t)blockIdx.y * kBY + threadIdx.y;
-    const int64_t i = blockIdx.z;
+    const int64_t i = v.i0 + blockIdx.z;
     if (k >= v.d[2] || j >= v.d[1]) return;
     double *p = v.p + v.at(i, j, k);
     p[0] = p[0] / kEps0;
@@ -55,9 +55,9 @@ __global__ __launch_bounds__(256) void k_div_eps0(View v)
 // g = (((b + cx*(u[i-1]+u[i+1])) + cy*(u[j-1]+u[j+1])) + cz*(u[k-1]+u[k+1])) / d
 // (reference cpp/PotentialSolver.cpp:3780-3786 and :3929-3935).
 __global__ __launch_bounds__(256) void k_smooth_colour(View u, View rhs, int64_t nj, int64_t nk,
-                                                       Coef c, double omega, int colour)
+                                                       Coef c, double omega, int colour, int64_t ilo)
 {
-    const int64_t i = 1 + (int64_t)blockIdx.z;
+    const int64_t i = ilo + (int64_t)blockIdx.z;
     const int64_t j = 1 + (int64_t)blockIdx.y * kBY + threadIdx.y;
     const int64_t m = (int64_t)blockIdx.x * kBX + threadIdx.x;
     const int64_t k = 1 + ((i + j + 1 + colour) & 1) + 2 * m;
@@ -119,14 +119,14 @@ __global__ __launch_bounds__(1024) void k_smooth_lds(View u, View rhs, int nI, i
 
 // Residual (reference cpp/PotentialSolver.cpp:3792-3805) with the workgroup's
 // sum of squares written to partials[linear block id].
-__global__ __launch_bounds__(256) void k_residual(View phi, View b, View R, Coef c,
-                                                  double *__restrict__ partials)
+__global__ __launch_bounds__(256) void k_residual(View phi, View b, View R, int64_t ni, Coef c,
+                                                  double *__restrict__ partials, int64_t ilo)
 {
     __shared__ double lds[4];
-    const int64_t ni = phi.d[0], nj = phi.d[1], nk = phi.d[2];
+    const int64_t nj = phi.d[1], nk = phi.d[2];
     const int64_t k = (int64_t)blockIdx.x * kBX + threadIdx.x;
     const int64_t j = (int64_t)blockIdx.y * kBY + threadIdx.y;
-    const int64_t i = blockIdx.z;
+    const int64_t i = ilo + blockIdx.z;
     double r = 0;
     if (k < nk && j < nj) {
         const double *p = phi.p + phi.at(i, j, k);
@@ -165,11 +165,11 @@ __global__ __launch_bounds__(256) void k_sumsq(const double *__restrict__ x, int
 
 // 27-point full weighting (reference cpp/PotentialSolver.cpp:3822-3839): terms
 // summed left to right, first index fastest, third slowest, then / 64.0.
-__global__ __launch_bounds__(256) void k_restrict27(View Rf, View Rc)
+__global__ __launch_bounds__(256) void k_restrict27(View Rf, View Rc, int64_t Ilo)
 {
     const int64_t K = (int64_t)blockIdx.x * kBX + threadIdx.x;
     const int64_t J = (int64_t)blockIdx.y * kBY + threadIdx.y;
-    const int64_t I = blockIdx.z;
+    const int64_t I = Ilo + blockIdx.z;
     if (K >= Rc.d[2] || J >= Rc.d[1]) return;
     const double *f = Rf.p + Rf.at(2 * I, 2 * J, 2 * K);
     double v;
@@ -202,11 +202,12 @@ __global__ __launch_bounds__(256) void k_restrict27(View Rf, View Rc)
 struct alignas(16) dpair { double x, y; };
 
 template <bool CORRECT>
-__global__ __launch_bounds__(256) void k_prolong(View ec, View out, int64_t nI, int64_t nJ, int64_t nK)
+__global__ __launch_bounds__(256) void k_prolong(View ec, View out, int64_t nI, int64_t nJ, int64_t nK,
+                                                 int64_t ilo, int64_t ihi)
 {
     const int64_t K = (int64_t)blockIdx.x * kBX + threadIdx.x;
     const int64_t J = (int64_t)blockIdx.y * kBY + threadIdx.y;
-    const int64_t I = blockIdx.z;
+    const int64_t I = (ilo >> 1) + blockIdx.z;  // cells whose fine planes 2I, 2I+1 meet [ilo, ihi)
     // fine points 0..n-2 per axis are written; cell K covers k = 2K, 2K+1
     if (2 * K > nK - 2 || 2 * J > nJ - 2) return;
     const double *c = ec.p + ec.at(I, J, K);
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void k_prolong(View ec, View out, int64_t nI, 
 #pragma unroll
     for (int di = 0; di < 2; di++) {
         const int64_t i = 2 * I + di;
-        if (i > nI - 2) continue;
+        if (i > nI - 2 || i < ilo || i >= ihi) continue;
 #pragma unroll
         for (int dj = 0; dj < 2; dj++) {
             const int64_t j = 2 * J + dj;
@@ -271,9 +272,9 @@ inline dim3 grid_for(int64_t nk, int64_t nj, int64_t ni)
 
 }  // namespace
 
-int64_t residual_partials(const int64_t n[3])
+int64_t residual_partials(const int64_t n[3], IRange r)
 {
-    dim3 g = grid_for(n[2], n[1], n[0]);
+    dim3 g = grid_for(n[2], n[1], r.hi - r.lo);
     return (int64_t)g.x * g.y * g.z;
 }
 
@@ -291,12 +292,14 @@ void div_eps0(hipStream_t s, View v)
 }
 
 void smooth_colour(hipStream_t s, View u, View rhs, const int64_t n[3], Coef c, double omega,
-                   int colour)
+                   int colour, IRange r)
 {
     if (n[0] < 3 || n[1] < 3 || n[2] < 3) return;
+    const int64_t lo = r.lo < 1 ? 1 : r.lo, hi = r.hi > n[0] - 1 ? n[0] - 1 : r.hi;
+    if (hi <= lo) return;
     const int64_t half = (n[2] - 2 + 1) / 2;  // k positions of one colour in a row, at most
-    hipLaunchKernelGGL(k_smooth_colour, grid_for(half, n[1] - 2, n[0] - 2), dim3(kBX, kBY), 0, s, u,
-                       rhs, n[1], n[2], c, omega, colour);
+    hipLaunchKernelGGL(k_smooth_colour, grid_for(half, n[1] - 2, hi - lo), dim3(kBX, kBY), 0, s, u, rhs,
+                       n[1], n[2], c, omega, colour, lo);
 }
 
 // Kernel choice for the smoother: the fused single-pass sweep pays once the level
@@ -313,13 +316,15 @@ static bool use_fused_sweep(const View &u)
     }();
     if (forced == 1) return false;
     if (forced == 2) return true;
-    return u.d[0] >= 64 && u.d[1] >= 64 && u.d[2] >= 64;
+    static const int min_dim = [] { const char *e = getenv("MG_FUSED_MIN"); return e ? atoi(e) : 128; }();
+    return u.d[0] >= 4 && u.d[1] >= min_dim && u.d[2] >= min_dim;
 }
 
 int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c,
-              double omega, int sweeps)
+              double omega, int sweeps, IRange r)
 {
     if (n[0] < 3 || n[1] < 3 || n[2] < 3) return 0;
+    const bool whole = u->i0 == 0 && r.lo == 0 && r.hi == u->d[0] && rhs.i0 == 0;
     // small enough for one workgroup's LDS: all sweeps in a single launch
     const size_t lds_bytes = sizeof(double) * (size_t)(u->d[0] * u->d[1] * u->d[2] + n[0] * rhs.d[1] * rhs.d[2]);
     static const bool lds_ok = [] {
@@ -328,7 +333,7 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
         return hipFuncSetAttribute((const void *)k_smooth_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    kLdsSmoothMaxBytes) == hipSuccess;
     }();
-    if (lds_ok && lds_bytes <= (size_t)kLdsSmoothMaxBytes && sweeps > 0) {
+    if (whole && lds_ok && lds_bytes <= (size_t)kLdsSmoothMaxBytes && sweeps > 0) {
         hipLaunchKernelGGL(k_smooth_lds, dim3(1), dim3(1024), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
                            (int)n[2], c, omega, sweeps);
         return 1;
@@ -336,22 +341,23 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
     const bool fused = alt && alt->p && use_fused_sweep(*u);
     for (int sw = 0; sw < sweeps; sw++) {
         if (fused) {
-            sweep_rb_fused(s, *u, *alt, rhs, n, c, omega);
+            sweep_rb_fused(s, *u, *alt, rhs, n, c, omega, r);
             View t = *u;
             *u = *alt;
             *alt = t;
         } else {
-            smooth_colour(s, *u, rhs, n, c, omega, 0);
-            smooth_colour(s, *u, rhs, n, c, omega, 1);
+            smooth_colour(s, *u, rhs, n, c, omega, 0, r);
+            smooth_colour(s, *u, rhs, n, c, omega, 1, r);
         }
     }
     return fused ? sweeps : 2 * sweeps;
 }
 
-void residual(hipStream_t s, View phi, View b, View R, Coef c, double *partials)
+void residual(hipStream_t s, View phi, View b, View R, const int64_t n[3], Coef c, double *partials,
+              IRange r)
 {
-    hipLaunchKernelGGL(k_residual, grid_for(phi.d[2], phi.d[1], phi.d[0]), dim3(kBX, kBY), 0, s, phi,
-                       b, R, c, partials);
+    hipLaunchKernelGGL(k_residual, grid_for(n[2], n[1], r.hi - r.lo), dim3(kBX, kBY), 0, s, phi, b, R,
+                       n[0], c, partials, r.lo);
 }
 
 void sum_partials(hipStream_t s, const double *partials, int64_t count, double *out)
@@ -364,22 +370,33 @@ void sumsq(hipStream_t s, const double *x, int64_t count, double *partials)
     hipLaunchKernelGGL(k_sumsq, dim3(sumsq_blocks(count)), dim3(256), 0, s, x, count, partials);
 }
 
-void restrict27(hipStream_t s, View Rf, View Rc)
+void restrict27(hipStream_t s, View Rf, View Rc, const int64_t nf[3], IRange rc)
 {
-    hipLaunchKernelGGL(k_restrict27, grid_for(Rc.d[2], Rc.d[1], Rc.d[0]), dim3(kBX, kBY), 0, s, Rf,
-                       Rc);
+    (void)nf;
+    if (rc.hi <= rc.lo) return;
+    hipLaunchKernelGGL(k_restrict27, grid_for(Rc.d[2], Rc.d[1], rc.hi - rc.lo), dim3(kBX, kBY), 0, s, Rf,
+                       Rc, rc.lo);
 }
 
-void prolong(hipStream_t s, View ec, View ef, const int64_t n[3])
+static void launch_prolong(hipStream_t s, bool correct, View ec, View out, const int64_t n[3], IRange r)
 {
-    hipLaunchKernelGGL(k_prolong<false>, grid_for(n[2] / 2, n[1] / 2, n[0] / 2), dim3(kBX, kBY), 0, s, ec,
-                       ef, n[0], n[1], n[2]);
+    if (r.hi <= r.lo) return;
+    const int64_t cells = ((r.hi - 1) >> 1) - (r.lo >> 1) + 1;
+    const dim3 g = grid_for(n[2] / 2, n[1] / 2, cells);
+    if (correct)
+        hipLaunchKernelGGL(k_prolong<true>, g, dim3(kBX, kBY), 0, s, ec, out, n[0], n[1], n[2], r.lo, r.hi);
+    else
+        hipLaunchKernelGGL(k_prolong<false>, g, dim3(kBX, kBY), 0, s, ec, out, n[0], n[1], n[2], r.lo, r.hi);
 }
 
-void prolong_correct(hipStream_t s, View ec, View phi, const int64_t n[3])
+void prolong(hipStream_t s, View ec, View ef, const int64_t n[3], IRange r)
 {
-    hipLaunchKernelGGL(k_prolong<true>, grid_for(n[2] / 2, n[1] / 2, n[0] / 2), dim3(kBX, kBY), 0, s, ec,
-                       phi, n[0], n[1], n[2]);
+    launch_prolong(s, false, ec, ef, n, r);
+}
+
+void prolong_correct(hipStream_t s, View ec, View phi, const int64_t n[3], IRange r)
+{
+    launch_prolong(s, true, ec, phi, n, r);
 }
 
 void correct(hipStream_t s, double *phi, const double *eps, int64_t count)

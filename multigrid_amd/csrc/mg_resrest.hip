@@ -35,9 +35,10 @@ __device__ __forceinline__ double wave_sum64(double v)
 // WJ x 2*WKP window of fine points; residual valid on the window minus one ring;
 // owned (norm, restriction centres) = window minus two rings.
 template <int WJ, int WKP, int D, bool STORE_RF>
-__global__ __launch_bounds__(256) void k_residual_restrict(View phi, View b, View Rf, View Rc, Coef c,
-                                                           double *__restrict__ partials, int CI,
-                                                           int nchunks, int tiles_k)
+__global__ __launch_bounds__(256) void k_residual_restrict(View phi, View b, View Rf, View Rc, int nI,
+                                                           Coef c, double *__restrict__ partials,
+                                                           int CI, int nchunks, int tiles_k, int rlo,
+                                                           int rhi)
 {
     static_assert(WKP == 32, "row shuffles assume 32 lanes per row");
     constexpr int WK = 2 * WKP;
@@ -54,19 +55,21 @@ __global__ __launch_bounds__(256) void k_residual_restrict(View phi, View b, Vie
     const int tile = blockIdx.x / nchunks;
     const int tk = tile % tiles_k, tj = tile / tiles_k;
     const int j0 = tj * TJ - 2, k0 = tk * TK - 2;
-    const int nI = (int)phi.d[0], nJ = (int)phi.d[1], nK = (int)phi.d[2];
-    const int cI = (int)Rc.d[0], cJ = (int)Rc.d[1], cK = (int)Rc.d[2];
-    const int ia = chunk * CI;
-    const int ib = min(ia + CI, nI);
+    const int nJ = (int)phi.d[1], nK = (int)phi.d[2];
+    const int cI = nI >> 1, cJ = (int)Rc.d[1], cK = (int)Rc.d[2];
+    const int ia = rlo + chunk * CI;
+    const int ib = min(ia + CI, rhi);
     double acc = 0.0;
     if (ia < ib) {
         const int kk = k0 + 2 * m;
         const int kkc = min(max(kk, 0), (nK - 1) & ~1);
         // row index rq = -1..Q: the lane's Q rows plus the row above and below its block
         auto row_of = [&](int rq) { return g * Q + rq; };
+        // stored plane range of phi and b (views may be slabs), global indices
+        const int vlo = (int)max(phi.i0, b.i0), vhi = (int)min(phi.i_end(), b.i_end()) - 1;
         auto load = [&](const View &v, int i, int rq) -> d2 {
             const int j = min(max(j0 + row_of(rq), 0), nJ - 1);
-            const int ic = min(max(i, 0), nI - 1);
+            const int ic = min(max(i, vlo), vhi);
             return *reinterpret_cast<const d2 *>(v.p + v.at(ic, j, kkc));
         };
 
@@ -191,18 +194,19 @@ struct Geometry {
     unsigned grid;
 };
 
-Geometry geometry(const int64_t n[3])
+Geometry geometry(const int64_t n[3], IRange r)
 {
     constexpr int TJ = 28, TK = 60;
     Geometry g;
+    const int64_t planes = r.hi - r.lo;
     g.tiles_j = (int)((n[1] + TJ - 1) / TJ);
     g.tiles_k = (int)((n[2] + TK - 1) / TK);
     int nchunks = 8;
-    while ((int64_t)nchunks * g.tiles_j * g.tiles_k < 1024 && n[0] / (nchunks * 2) >= 8) nchunks *= 2;
-    if (n[0] < 16) nchunks = 1;
+    while ((int64_t)nchunks * g.tiles_j * g.tiles_k < 1024 && planes / (nchunks * 2) >= 8) nchunks *= 2;
+    if (planes < 16) nchunks = 1;
     static const int want = [] { const char *e = getenv("MG_RR_CHUNKS"); return e ? atoi(e) : 0; }();
     if (want > 0) nchunks = want;
-    int CI = (int)((n[0] + nchunks - 1) / nchunks);
+    int CI = (int)((planes + nchunks - 1) / nchunks);
     CI += CI & 1;  // chunks start on even planes: a coarse plane's three fine planes stay together
     g.nchunks = nchunks;
     g.CI = CI;
@@ -212,20 +216,21 @@ Geometry geometry(const int64_t n[3])
 
 }  // namespace
 
-int64_t residual_restrict_partials(const int64_t n[3]) { return geometry(n).grid; }
+int64_t residual_restrict_partials(const int64_t n[3], IRange r) { return geometry(n, r).grid; }
 
-// R_c = restrict27(residual(phi, b)), partials[0..residual_restrict_partials) = per-workgroup
-// sums of squares of the fine residual.  Rf.p may be null (the fine residual is then
-// never written).
-void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, Coef c, double *partials)
+// Coarse planes of R_c = restrict27(residual(phi, b)) for the fine planes r (r.lo even), and
+// partials[0..residual_restrict_partials) = per-workgroup sums of squares of the fine residual
+// over planes r.  Rf.p may be null (the fine residual is then never written).
+void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const int64_t n[3], Coef c,
+                       double *partials, IRange r)
 {
-    const Geometry g = geometry(phi.d);
+    const Geometry g = geometry(n, r);
     if (Rf.p)
         hipLaunchKernelGGL((k_residual_restrict<32, 32, 2, true>), dim3(g.grid), dim3(256), 0, s, phi, b,
-                           Rf, Rc, c, partials, g.CI, g.nchunks, g.tiles_k);
+                           Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi);
     else
         hipLaunchKernelGGL((k_residual_restrict<32, 32, 2, false>), dim3(g.grid), dim3(256), 0, s, phi, b,
-                           Rf, Rc, c, partials, g.CI, g.nchunks, g.tiles_k);
+                           Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi);
 }
 
 }  // namespace mgk

@@ -45,7 +45,7 @@ __device__ __forceinline__ d2 put(d2 v, int e, double x)
 template <int WJ, int WKP, int D>
 __global__ __launch_bounds__(256) void k_sweep_rb(View uin, View uout, View rhs, int nI, int nJ,
                                                   int nK, Coef c, double omega, int CI, int nchunks,
-                                                  int tiles_k)
+                                                  int tiles_k, int rlo, int rhi)
 {
     constexpr int WK = 2 * WKP;
     constexpr int TJ = WJ - 4, TK = WK - 4;
@@ -61,10 +61,13 @@ __global__ __launch_bounds__(256) void k_sweep_rb(View uin, View uout, View rhs,
     const int tile = blockIdx.x / nchunks;
     const int tk = tile % tiles_k, tj = tile / tiles_k;
     const int j0 = tj * TJ - 2, k0 = tk * TK - 2;
-    const int uI = (int)uin.d[0], uJ = (int)uin.d[1], uK = (int)uin.d[2];
-    const int rI = (int)rhs.d[0], rJ = (int)rhs.d[1], rK = (int)rhs.d[2];
-    const int ia = chunk * CI;
-    const int ib = min(ia + CI, uI);
+    const int uJ = (int)uin.d[1], uK = (int)uin.d[2];
+    const int rJ = (int)rhs.d[1], rK = (int)rhs.d[2];
+    // stored plane ranges of the (possibly slab) views, global indices
+    const int ulo = (int)uin.i0, uhi = (int)uin.i_end() - 1;
+    const int blo = (int)rhs.i0, bhi = (int)rhs.i_end() - 1;
+    const int ia = rlo + chunk * CI;
+    const int ib = min(ia + CI, rhi);
     if (ia >= ib) return;  // uniform per workgroup
     const int kk = k0 + 2 * m;  // first column of this lane's pairs
 
@@ -75,12 +78,12 @@ __global__ __launch_bounds__(256) void k_sweep_rb(View uin, View uout, View rhs,
     const int kkr = min(max(kk, 0), (rK - 1) & ~1);
     auto load_u = [&](int i, int q) -> d2 {
         const int j = min(max(j0 + q * RPP + rr, 0), uJ - 1);
-        const int ic = min(max(i, 0), uI - 1);
+        const int ic = min(max(i, ulo), uhi);
         return *reinterpret_cast<const d2 *>(uin.p + uin.at(ic, j, kku));
     };
     auto load_b = [&](int i, int q) -> d2 {
         const int j = min(max(j0 + q * RPP + rr, 0), rJ - 1);
-        const int ic = min(max(i, 0), rI - 1);
+        const int ic = min(max(i, blo), bhi);
         return *reinterpret_cast<const d2 *>(rhs.p + rhs.at(ic, j, kkr));
     };
 
@@ -192,27 +195,30 @@ static int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
-// One full red-black sweep u_in -> u_out over 1..n-2 per axis (n = level size);
-// every other element of the arrays is copied through unchanged.
+// One full red-black sweep u_in -> u_out: planes r of u_out, updated over 1..n-2 per axis
+// (n = level size); every other element of those planes is copied through unchanged.
 void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c,
-                    double omega)
+                    double omega, IRange r)
 {
     constexpr int WJ = 32, WKP = 32;
     constexpr int TJ = WJ - 4, TK = 2 * WKP - 4;
     static const int depth = env_int("MG_SWEEP_D", 2);         // tuning knobs (A/B runs)
     static const int want_chunks = env_int("MG_SWEEP_CHUNKS", 0);
+    const int64_t planes = r.hi - r.lo;
+    if (planes <= 0) return;
     const int tiles_j = (int)((uin.d[1] + TJ - 1) / TJ);
     const int tiles_k = (int)((uin.d[2] + TK - 1) / TK);
     // i-chunks: a multiple of 8 (one group per XCD) and enough workgroups to fill 256 CUs
     int nchunks = 8;
-    while ((int64_t)nchunks * tiles_j * tiles_k < 1024 && uin.d[0] / (nchunks * 2) >= 8) nchunks *= 2;
-    if (uin.d[0] < 16) nchunks = 1;
+    while ((int64_t)nchunks * tiles_j * tiles_k < 1024 && planes / (nchunks * 2) >= 8) nchunks *= 2;
+    if (planes < 16) nchunks = 1;
     if (want_chunks > 0) nchunks = want_chunks;
-    const int CI = (int)((uin.d[0] + nchunks - 1) / nchunks);
+    const int CI = (int)((planes + nchunks - 1) / nchunks);
     const unsigned grid = (unsigned)(nchunks * tiles_j * tiles_k);
 #define LAUNCH(D)                                                                                  \
     hipLaunchKernelGGL((k_sweep_rb<WJ, WKP, D>), dim3(grid), dim3(256), 0, s, uin, uout, rhs,      \
-                       (int)n[0], (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k)
+                       (int)n[0], (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k, (int)r.lo, \
+                       (int)r.hi)
     if (depth <= 1) LAUNCH(1);
     else if (depth == 2) LAUNCH(2);
     else LAUNCH(3);
