@@ -196,6 +196,57 @@ int mg_op_smooth_rb(int device, const int64_t n[3], const int64_t u_dims[3],
 /* sum of x[p]^2 (cpp/PotentialSolver.cpp:3810-3816) */
 int mg_op_sumsq(int device, int64_t count, const double *x, double *out);
 
+/* ---- device-level operators for a slab-partitioned solve ------------------
+ * One process per GPU owns a slab of i-planes of every distributed level plus
+ * halo planes; the host orchestrates (multigrid_amd/dist.py) and moves halo
+ * planes between ranks with RCCL send/recv.  These entry points run ONE
+ * operator on arrays the caller owns in device memory, asynchronously on the
+ * caller's HIP stream.  They have no counterpart in the reference, which is a
+ * single-threaded CPU program; each applies the same loop nest as the solver
+ * (see the mg_op_* twin for the reference lines) to a range of global planes.
+ *
+ * mg_dev_array describes planes [i0, i0+planes) of a level's global array:
+ * fp64, [plane][nj rows][pitch], pitch = nk rounded up to even, 16-byte
+ * aligned base.  n[3] is always the GLOBAL size of the level the loop bounds
+ * refer to; lo/hi are global plane indices [lo, hi) the call produces. */
+typedef struct mg_dev_array {
+    void *ptr;
+    int64_t planes, nj, nk;
+    int64_t i0;
+} mg_dev_array;
+
+/* Row pitch in doubles for rows of nk nodes. */
+int64_t mg_dev_pitch(int64_t nk);
+/* {cx, cy, cz, 2cx+2cy+2cz} of level `level` (cpp/PotentialSolver.cpp:3728-3750); host only. */
+int mg_level_coef(const double dh[3], int level, double out[4]);
+/* v /= EPS_0 over the whole array. */
+int mg_dev_div_eps0(void *stream, const mg_dev_array *v);
+/* `sweeps` red-black sweeps of planes [lo,hi) of u (right-hand side rhs, level size n).
+ * The sweep may be out of place: alt has u's shape; *result_in_alt = 1 when the result
+ * landed in alt (the caller swaps its references).  Out-of-place sweeps read planes
+ * [lo-2, hi+2) of u as far as they exist, so with halos two planes wide one sweep needs
+ * one halo exchange.  sweeps > 1 is meant for arrays held whole on one GPU. */
+int mg_dev_smooth_rb(void *stream, const mg_dev_array *u, const mg_dev_array *alt,
+                     const mg_dev_array *rhs, const int64_t n[3], const double c[4], double omega,
+                     int sweeps, int64_t lo, int64_t hi, int *result_in_alt);
+/* Coarse planes [lo/2, (hi+1)/2) of Rc = restrict27(residual(phi, b)) for fine planes
+ * [lo,hi) (lo even; hi even unless it is the last plane of the level), per-workgroup partial sums of the squared fine
+ * residual into partials (capacity `capacity` doubles); *count = partials written.
+ * Reads phi planes [lo-2, hi+1). */
+int mg_dev_residual_restrict(void *stream, const mg_dev_array *phi, const mg_dev_array *b,
+                             const mg_dev_array *Rc, const int64_t n[3], const double c[4],
+                             double *partials, int64_t capacity, int64_t lo, int64_t hi,
+                             int64_t *count);
+/* out[0] = sum(partials[0..count)), fixed order. */
+int mg_dev_sum_partials(void *stream, const double *partials, int64_t count, double *out);
+/* Coarse planes [lo,hi) of Rc = restrict27(Rf); nf = size of the fine level. Reads Rf planes [2lo-1, 2hi). */
+int mg_dev_restrict27(void *stream, const mg_dev_array *Rf, const mg_dev_array *Rc,
+                      const int64_t nf[3], int64_t lo, int64_t hi);
+/* Fine planes [lo,hi): out = P(ec) (correct == 0, out = eps of the finer level) or
+ * out -= P(ec) (correct != 0, out = phi); n = size of the fine level.  Reads ec planes [lo/2, (hi-1)/2 + 2). */
+int mg_dev_prolong(void *stream, const mg_dev_array *ec, const mg_dev_array *out,
+                   const int64_t n[3], int64_t lo, int64_t hi, int correct);
+
 #ifdef __cplusplus
 }
 #endif

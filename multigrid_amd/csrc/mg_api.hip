@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -775,6 +776,168 @@ int mg_op_sumsq(int device, int64_t count, const double *x, double *out)
     mgk::sumsq(nullptr, dx, count, partials);
     HIP_TRY(hipGetLastError());
     return reduce_to_host(partials, np, out);
+}
+
+/* ------------------------------------------------------------------------ */
+/* device-level operators (slab partition)                                   */
+
+namespace {
+
+int dev_view(const mg_dev_array *a, View *v, const char *what, bool allow_null = false)
+{
+    if (!a) return fail(MG_ERR_INVALID, "%s: null array descriptor", what);
+    if (!a->ptr && !allow_null) return fail(MG_ERR_INVALID, "%s: null device pointer", what);
+    if (a->planes < 1 || a->nj < 1 || a->nk < 1 || a->i0 < 0)
+        return fail(MG_ERR_INVALID, "%s: bad array shape", what);
+    if (((uintptr_t)a->ptr) & 15) return fail(MG_ERR_INVALID, "%s: device pointer not 16-byte aligned", what);
+    v->p = (double *)a->ptr;
+    v->d[0] = a->planes;
+    v->d[1] = a->nj;
+    v->d[2] = a->nk;
+    v->sj = mgk::pitch_for(a->nk);
+    v->si = v->sj * a->nj;
+    v->i0 = a->i0;
+    return MG_OK;
+}
+
+// planes [lo, hi) intersected with [0, gmax) must be stored in v
+int need_planes(const View &v, int64_t lo, int64_t hi, int64_t gmax, const char *what)
+{
+    if (lo < 0) lo = 0;
+    if (hi > gmax) hi = gmax;
+    if (lo < hi && (lo < v.i0 || hi > v.i_end()))
+        return fail(MG_ERR_INVALID, "%s: needs planes [%lld,%lld) but the array holds [%lld,%lld)", what,
+                    (long long)lo, (long long)hi, (long long)v.i0, (long long)v.i_end());
+    return MG_OK;
+}
+
+Coef coef4(const double c[4])
+{
+    Coef k;
+    k.cx = c[0];
+    k.cy = c[1];
+    k.cz = c[2];
+    k.d = c[3];
+    return k;
+}
+
+}  // namespace
+
+int64_t mg_dev_pitch(int64_t nk) { return mgk::pitch_for(nk); }
+
+int mg_level_coef(const double dh[3], int level, double out[4])
+{
+    if (!dh || !out || level < 0 || level >= MG_MAX_LEVELS) return fail(MG_ERR_INVALID, "bad argument");
+    const Coef c = level_coef(dh, level);
+    out[0] = c.cx;
+    out[1] = c.cy;
+    out[2] = c.cz;
+    out[3] = c.d;
+    return MG_OK;
+}
+
+int mg_dev_div_eps0(void *stream, const mg_dev_array *v)
+{
+    View a;
+    TRY(dev_view(v, &a, "mg_dev_div_eps0"));
+    mgk::div_eps0((hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return MG_OK;
+}
+
+int mg_dev_smooth_rb(void *stream, const mg_dev_array *u, const mg_dev_array *alt, const mg_dev_array *rhs,
+                     const int64_t n[3], const double c[4], double omega, int sweeps, int64_t lo, int64_t hi,
+                     int *result_in_alt)
+{
+    if (!n || !c || !result_in_alt || sweeps < 0) return fail(MG_ERR_INVALID, "bad argument");
+    View vu, va, vr;
+    TRY(dev_view(u, &vu, "mg_dev_smooth_rb(u)"));
+    TRY(dev_view(alt, &va, "mg_dev_smooth_rb(alt)"));
+    TRY(dev_view(rhs, &vr, "mg_dev_smooth_rb(rhs)"));
+    if (va.d[0] != vu.d[0] || va.d[1] != vu.d[1] || va.d[2] != vu.d[2] || va.i0 != vu.i0)
+        return fail(MG_ERR_INVALID, "mg_dev_smooth_rb: alt must have the shape of u");
+    if (lo < vu.i0 || hi > vu.i_end() || lo > hi) return fail(MG_ERR_INVALID, "mg_dev_smooth_rb: bad plane range");
+    const int64_t ulo = lo < 1 ? 1 : lo, uhi = hi > n[0] - 1 ? n[0] - 1 : hi;  // planes actually updated
+    if (ulo < uhi) {
+        // red update of planes ulo-1..uhi reads planes ulo-2..uhi+1 of u; rhs is read on updated planes
+        TRY(need_planes(vu, ulo - 2, uhi + 2, n[0], "mg_dev_smooth_rb(u)"));
+        TRY(need_planes(vr, ulo - 1, uhi + 1, n[0] - 1, "mg_dev_smooth_rb(rhs)"));
+    }
+    const double *before = vu.p;
+    mgk::smooth_rb((hipStream_t)stream, &vu, &va, vr, n, coef4(c), omega, sweeps, IRange{lo, hi});
+    HIP_TRY(hipGetLastError());
+    *result_in_alt = vu.p != before;
+    return MG_OK;
+}
+
+int mg_dev_residual_restrict(void *stream, const mg_dev_array *phi, const mg_dev_array *b, const mg_dev_array *Rc,
+                             const int64_t n[3], const double c[4], double *partials, int64_t capacity,
+                             int64_t lo, int64_t hi, int64_t *count)
+{
+    if (!n || !c || !partials || !count) return fail(MG_ERR_INVALID, "null argument");
+    View vp, vb, vc;
+    TRY(dev_view(phi, &vp, "mg_dev_residual_restrict(phi)"));
+    TRY(dev_view(b, &vb, "mg_dev_residual_restrict(b)"));
+    TRY(dev_view(Rc, &vc, "mg_dev_residual_restrict(Rc)"));
+    if ((lo & 1) || lo < 0 || hi > n[0] || lo >= hi) return fail(MG_ERR_INVALID, "mg_dev_residual_restrict: bad plane range");
+    if ((hi & 1) && hi != n[0]) return fail(MG_ERR_INVALID, "mg_dev_residual_restrict: hi must be even or the level's last plane");
+    TRY(need_planes(vp, lo - 2, hi + 1, n[0], "mg_dev_residual_restrict(phi)"));
+    TRY(need_planes(vb, lo - 1, hi, n[0], "mg_dev_residual_restrict(b)"));
+    const int64_t clo = lo >> 1, chi = (hi >> 1) < (n[0] >> 1) ? (hi >> 1) : (n[0] >> 1);
+    TRY(need_planes(vc, clo, chi, n[0] >> 1, "mg_dev_residual_restrict(Rc)"));
+    const IRange r{lo, hi};
+    const int64_t np = mgk::residual_restrict_partials(n, r);
+    if (np > capacity) return fail(MG_ERR_INVALID, "mg_dev_residual_restrict: partials buffer too small (%lld > %lld)", (long long)np, (long long)capacity);
+    View none = vp;
+    none.p = nullptr;
+    mgk::residual_restrict((hipStream_t)stream, vp, vb, none, vc, n, coef4(c), partials, r);
+    HIP_TRY(hipGetLastError());
+    *count = np;
+    return MG_OK;
+}
+
+int mg_dev_sum_partials(void *stream, const double *partials, int64_t count, double *out)
+{
+    if (!partials || !out || count < 0) return fail(MG_ERR_INVALID, "bad argument");
+    mgk::sum_partials((hipStream_t)stream, partials, count, out);
+    HIP_TRY(hipGetLastError());
+    return MG_OK;
+}
+
+int mg_dev_restrict27(void *stream, const mg_dev_array *Rf, const mg_dev_array *Rc, const int64_t nf[3],
+                      int64_t lo, int64_t hi)
+{
+    if (!nf) return fail(MG_ERR_INVALID, "null argument");
+    View vf, vc;
+    TRY(dev_view(Rf, &vf, "mg_dev_restrict27(Rf)"));
+    TRY(dev_view(Rc, &vc, "mg_dev_restrict27(Rc)"));
+    if (lo < 0 || hi > (nf[0] >> 1) || lo > hi) return fail(MG_ERR_INVALID, "mg_dev_restrict27: bad plane range");
+    if (lo < hi) {
+        TRY(need_planes(vc, lo, hi, nf[0] >> 1, "mg_dev_restrict27(Rc)"));
+        TRY(need_planes(vf, lo == 0 ? 0 : 2 * lo - 1, 2 * hi, nf[0], "mg_dev_restrict27(Rf)"));
+    }
+    mgk::restrict27((hipStream_t)stream, vf, vc, nf, IRange{lo, hi});
+    HIP_TRY(hipGetLastError());
+    return MG_OK;
+}
+
+int mg_dev_prolong(void *stream, const mg_dev_array *ec, const mg_dev_array *out, const int64_t n[3], int64_t lo,
+                   int64_t hi, int correct)
+{
+    if (!n) return fail(MG_ERR_INVALID, "null argument");
+    View vc, vo;
+    TRY(dev_view(ec, &vc, "mg_dev_prolong(ec)"));
+    TRY(dev_view(out, &vo, "mg_dev_prolong(out)"));
+    if (lo < 0 || lo > hi) return fail(MG_ERR_INVALID, "mg_dev_prolong: bad plane range");
+    const int64_t whi = hi > n[0] - 1 ? n[0] - 1 : hi;  // planes 0..n-2 are written
+    if (lo < whi) {
+        TRY(need_planes(vo, lo, whi, n[0], "mg_dev_prolong(out)"));
+        TRY(need_planes(vc, lo >> 1, ((whi - 1) >> 1) + 2, (n[0] >> 1) + 1, "mg_dev_prolong(ec)"));
+    }
+    if (correct) mgk::prolong_correct((hipStream_t)stream, vc, vo, n, IRange{lo, hi});
+    else mgk::prolong((hipStream_t)stream, vc, vo, n, IRange{lo, hi});
+    HIP_TRY(hipGetLastError());
+    return MG_OK;
 }
 
 }  // extern "C"

@@ -346,7 +346,15 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
             *u = *alt;
             *alt = t;
         } else {
-            smooth_colour(s, *u, rhs, n, c, omega, 0, r);
+            // Red also on the plane next to the range on either side (as far as its own
+            // neighbours are stored): in a slab partition those are halo planes whose red
+            // values the black update below needs, and computing them here instead of
+            // receiving them lets one halo exchange per sweep suffice.  For a whole array
+            // the wider range clips back to 1..n-2.
+            IRange red{r.lo - 1, r.hi + 1};
+            if (red.lo < u->i0 + 1) red.lo = u->i0 + 1;
+            if (red.hi > u->i_end() - 1) red.hi = u->i_end() - 1;
+            smooth_colour(s, *u, rhs, n, c, omega, 0, red);
             smooth_colour(s, *u, rhs, n, c, omega, 1, r);
         }
     }

@@ -65,11 +65,10 @@ __global__ __launch_bounds__(256) void k_residual_restrict(View phi, View b, Vie
         const int kkc = min(max(kk, 0), (nK - 1) & ~1);
         // row index rq = -1..Q: the lane's Q rows plus the row above and below its block
         auto row_of = [&](int rq) { return g * Q + rq; };
-        // stored plane range of phi and b (views may be slabs), global indices
-        const int vlo = (int)max(phi.i0, b.i0), vhi = (int)min(phi.i_end(), b.i_end()) - 1;
+        // loads clamp to the planes each view stores (views may be slabs with different halos)
         auto load = [&](const View &v, int i, int rq) -> d2 {
             const int j = min(max(j0 + row_of(rq), 0), nJ - 1);
-            const int ic = min(max(i, vlo), vhi);
+            const int ic = min(max(i, (int)v.i0), (int)v.i_end() - 1);
             return *reinterpret_cast<const d2 *>(v.p + v.at(ic, j, kkc));
         };
 

@@ -1,0 +1,420 @@
+"""Slab-partitioned multigrid V-cycle: one process per GPU, halo planes over
+torch.distributed (backend "nccl" = RCCL over xGMI on a GPU node; "gloo" works too).
+
+The reference is a single-threaded CPU program; nothing here has a counterpart in it.
+What is distributed is the same cycle the single-GPU library runs
+(reference cpp/PotentialSolver.cpp:3756-4216), operator by operator, with results
+bit-identical to the undivided red-black cycle:
+
+  * the i axis (slowest, planes contiguous) of every level l < cut is split into slabs
+    whose boundaries are multiples of 2^cut fine planes, so coarse slabs nest;
+  * every rank stores its planes plus halo planes (2 for phi/eps, 1 for right-hand
+    sides).  A red-black sweep recomputes the red update of the first halo plane on
+    either side, so ONE exchange of two planes per side per sweep replaces an exchange
+    after every colour;
+  * the sum of squared residuals is all-reduced once per cycle;
+  * level `cut` and everything below it is gathered onto rank 0, solved there on
+    whole arrays, and eps_cut is scattered back.
+
+The orchestration below is backend-agnostic: `ops` runs one operator on local slabs
+(HipOps: the mg_dev_* entry points of libmg_hip on device tensors).  There is no CPU
+compute backend in the product; the test-suite plugs in its CPU oracle to check the
+partition and the exchange schedule.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+# --------------------------------------------------------------------------- plan
+
+class SlabPlan:
+    """Who owns which planes of which level.  Pure arithmetic; no device, no comm."""
+
+    def __init__(self, n0, depth, world, cut=None, cut_size=128):
+        self.n0 = tuple(int(a) for a in n0)
+        self.depth = int(depth)
+        self.world = int(world)
+        L = self.depth
+        if (min(self.n0) >> L) < 3:
+            raise ValueError("grid too small for this depth")
+        if cut is None:  # first level small enough to live on one GPU, at least 1
+            cut = next((l for l in range(1, L + 1) if (self.n0[0] >> l) <= cut_size), L)
+        if not 1 <= cut <= L:
+            raise ValueError("cut level must be in 1..depth")
+        self.cut = cut
+        align = 1 << cut
+        base = ((self.n0[0] - 1) // self.world) // align * align
+        if base < align:
+            raise ValueError(f"{self.n0[0]} planes over {self.world} ranks leave fewer than "
+                             f"2^{cut} fine planes per rank; lower the cut level or the rank count")
+        self.bounds = [r * base for r in range(self.world)] + [self.n0[0]]  # fine-plane boundaries
+
+    def level_n(self, l):
+        return tuple(a >> l for a in self.n0)
+
+    def planes(self, l, kind):
+        """Global plane count of an array of level l: 'eps' arrays of l >= 1 have one extra node."""
+        n = self.n0[0] >> l
+        return n + 1 if (kind == "eps" and l >= 1) else n
+
+    def dims(self, l, kind):
+        n = self.level_n(l)
+        return tuple(a + 1 for a in n) if (kind == "eps" and l >= 1) else n
+
+    def own(self, l, kind, rank):
+        """Planes [lo, hi) of level l that `rank` owns (the last rank takes the tail)."""
+        lo = self.bounds[rank] >> l
+        hi = self.planes(l, kind) if rank == self.world - 1 else self.bounds[rank + 1] >> l
+        return lo, hi
+
+    def stored(self, l, kind, rank, halo):
+        """Planes [lo, hi) a rank stores: owned plus `halo` planes per side, clipped to the array."""
+        lo, hi = self.own(l, kind, rank)
+        return max(lo - halo, 0), min(hi + halo, self.planes(l, kind))
+
+
+# --------------------------------------------------------------------------- storage
+
+class Slab:
+    """Planes [i0, i0+planes) of a level's [i][j][k] array as a (planes, nj, pitch) fp64 tensor;
+    pitch = nk rounded up to even (the device library's row pitch)."""
+
+    def __init__(self, ops, i0, planes, nj, nk):
+        self.i0, self.nj, self.nk = int(i0), int(nj), int(nk)
+        self.pitch = (self.nk + 1) & ~1
+        self.t = ops.zeros((int(planes), self.nj, self.pitch))
+
+    @property
+    def planes(self):
+        return self.t.shape[0]
+
+    def rows(self, lo, hi):
+        """Tensor view of global planes [lo, hi)."""
+        return self.t[lo - self.i0:hi - self.i0]
+
+    def data(self, lo=None, hi=None):
+        """numpy copy of planes [lo,hi) without the pitch padding (tests / output)."""
+        lo = self.i0 if lo is None else lo
+        hi = self.i0 + self.planes if hi is None else hi
+        return self.rows(lo, hi)[:, :, :self.nk].cpu().numpy().copy()
+
+
+class HipOps:
+    """Local operators on device slabs through libmg_hip's mg_dev_* entry points."""
+
+    def __init__(self, device_index):
+        from . import libmg  # torch is already imported: both share one HIP runtime
+        self.libmg = libmg
+        self.lib = libmg.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipOps needs a GPU; there is no CPU fallback")
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        self.partials = torch.zeros(1 << 16, dtype=torch.float64, device=self.device)
+        self.scalar = torch.zeros(1, dtype=torch.float64, device=self.device)
+
+    # -- storage
+    def zeros(self, shape):
+        return torch.zeros(shape, dtype=torch.float64, device=self.device)
+
+    def upload(self, slab, array, lo):
+        """Dense host array of planes [lo, lo+len) -> slab."""
+        a = torch.from_numpy(np.ascontiguousarray(array))
+        slab.rows(lo, lo + a.shape[0])[:, :, :slab.nk].copy_(a)
+
+    # -- helpers
+    def _arr(self, s):
+        return self.libmg.MgDevArray(s.t.data_ptr(), s.planes, s.nj, s.nk, s.i0)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise self.libmg.MgError(rc, self.lib.mg_last_error().decode(errors="replace"))
+
+    def coef(self, dh, level):
+        out = (C.c_double * 4)()
+        self._check(self.lib.mg_level_coef((C.c_double * 3)(*dh), level, out))
+        return tuple(out)
+
+    # -- operators
+    def div_eps0(self, v):
+        self._check(self.lib.mg_dev_div_eps0(self._stream(), C.byref(self._arr(v))))
+
+    def smooth(self, u, alt, rhs, n, c, omega, sweeps, lo, hi):
+        """Returns True when the result landed in `alt`."""
+        flag = C.c_int(0)
+        self._check(self.lib.mg_dev_smooth_rb(self._stream(), C.byref(self._arr(u)), C.byref(self._arr(alt)),
+                                              C.byref(self._arr(rhs)), (C.c_int64 * 3)(*n), (C.c_double * 4)(*c),
+                                              omega, sweeps, lo, hi, C.byref(flag)))
+        return bool(flag.value)
+
+    def residual_restrict(self, phi, b, Rc, n, c, lo, hi):
+        """Returns a 1-element tensor holding this rank's sum of squared residuals."""
+        count = C.c_int64(0)
+        self._check(self.lib.mg_dev_residual_restrict(
+            self._stream(), C.byref(self._arr(phi)), C.byref(self._arr(b)), C.byref(self._arr(Rc)),
+            (C.c_int64 * 3)(*n), (C.c_double * 4)(*c), C.c_void_p(self.partials.data_ptr()),
+            self.partials.numel(), lo, hi, C.byref(count)))
+        self._check(self.lib.mg_dev_sum_partials(self._stream(), C.c_void_p(self.partials.data_ptr()),
+                                                 count.value, C.c_void_p(self.scalar.data_ptr())))
+        return self.scalar
+
+    def restrict27(self, Rf, Rc, nf, lo, hi):
+        self._check(self.lib.mg_dev_restrict27(self._stream(), C.byref(self._arr(Rf)), C.byref(self._arr(Rc)),
+                                               (C.c_int64 * 3)(*nf), lo, hi))
+
+    def prolong(self, ec, out, n, lo, hi, correct):
+        self._check(self.lib.mg_dev_prolong(self._stream(), C.byref(self._arr(ec)), C.byref(self._arr(out)),
+                                            (C.c_int64 * 3)(*n), lo, hi, int(correct)))
+
+    def sync(self):
+        torch.cuda.synchronize(self.device)
+
+
+# --------------------------------------------------------------------------- communication
+
+class Comm:
+    """Halo exchange, all-reduce and gather/scatter over torch.distributed point-to-point ops."""
+
+    def __init__(self, group=None, stage_through_host=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bytes_sent = 0
+        # gloo moves only host tensors point to point: device planes are staged through the host
+        if stage_through_host is None:
+            stage_through_host = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        self.stage = stage_through_host
+
+    def _run(self, ops):
+        if not ops:
+            return
+        if not self.stage or not any(o.tensor.is_cuda for o in ops):
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            return
+        staged, back = [], []
+        for o in ops:
+            h = o.tensor.cpu() if o.op is dist.isend else torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
+            staged.append(dist.P2POp(o.op, h, o.peer, self.group))
+            if o.op is dist.irecv:
+                back.append((o.tensor, h))
+        for w in dist.batch_isend_irecv(staged):
+            w.wait()
+        for dst, h in back:
+            dst.copy_(h)
+
+    def exchange(self, slab, own, width):
+        """Fill this rank's halo planes of `slab` (up to `width` per side) from the neighbours'
+        owned planes and send ours: planes are contiguous, one message per neighbour per direction."""
+        if self.world == 1:
+            return
+        lo, hi = own
+        ops = []
+        if self.rank + 1 < self.world:
+            w_up = min(width, slab.i0 + slab.planes - hi)  # halo planes stored above
+            ops.append(dist.P2POp(dist.isend, slab.rows(hi - width, hi), self.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, slab.rows(hi, hi + w_up), self.rank + 1, self.group))
+            assert w_up == width
+        if self.rank > 0:
+            ops.append(dist.P2POp(dist.isend, slab.rows(lo, lo + width), self.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, slab.rows(lo - width, lo), self.rank - 1, self.group))
+        self.bytes_sent += sum(o.tensor.numel() * 8 for o in ops if o.op is dist.isend)
+        self._run(ops)
+
+    def allreduce_sum(self, t):
+        if self.world > 1:
+            if self.stage and t.is_cuda:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def gather_planes(self, plan, l, kind, slab, full):
+        """Owned planes of every rank -> rank 0's whole array `full`."""
+        ops = []
+        if self.rank == 0:
+            lo, hi = plan.own(l, kind, 0)
+            full.rows(lo, hi).copy_(slab.rows(lo, hi))
+            for r in range(1, self.world):
+                lo, hi = plan.own(l, kind, r)
+                ops.append(dist.P2POp(dist.irecv, full.rows(lo, hi), r, self.group))
+        else:
+            lo, hi = plan.own(l, kind, self.rank)
+            ops.append(dist.P2POp(dist.isend, slab.rows(lo, hi), 0, self.group))
+        self._run(ops)
+
+    def scatter_planes(self, plan, l, kind, full, slab, halo):
+        """Rank 0's whole array -> every rank's stored planes (owned + halo)."""
+        ops = []
+        if self.rank == 0:
+            lo, hi = plan.stored(l, kind, 0, halo)
+            slab.rows(lo, hi).copy_(full.rows(lo, hi))
+            for r in range(1, self.world):
+                lo, hi = plan.stored(l, kind, r, halo)
+                ops.append(dist.P2POp(dist.isend, full.rows(lo, hi), r, self.group))
+        else:
+            lo, hi = plan.stored(l, kind, self.rank, halo)
+            ops.append(dist.P2POp(dist.irecv, slab.rows(lo, hi), 0, self.group))
+        self._run(ops)
+
+
+# --------------------------------------------------------------------------- solver
+
+REFERENCE_SCHEDULES = {1: (3, 50), 2: (3, 5, 50), 3: (3, 5, 5, 50), 4: (3, 5, 5, 5, 50),
+                       5: (1, 5, 5, 5, 5, 50)}  # reference cpp/PotentialSolver.cpp:2422.. :3759-3770
+
+
+def schedule(depth):
+    return REFERENCE_SCHEDULES.get(depth) or (1,) + (5,) * (depth - 1) + (50,)
+
+
+class DistSolver:
+    """One rank's share of a slab-partitioned multigrid solver (same state as a reference solver
+    object, divided).  Construct on every rank of the group with the same arguments."""
+
+    H_U, H_RHS = 2, 1  # halo planes of swept fields / of right-hand sides
+
+    def __init__(self, n0, dh, depth, ops, comm, nu=None, omega=1.4, cut=None, cut_size=128):
+        self.ops, self.comm = ops, comm
+        self.rank, self.world = comm.rank, comm.world
+        self.plan = SlabPlan(n0, depth, self.world, cut, cut_size)
+        self.depth, self.cut = depth, self.plan.cut
+        self.dh = tuple(float(a) for a in dh)
+        self.nu = tuple(nu) if nu is not None else schedule(depth)
+        self.omega = omega
+        self.coef = [ops.coef(self.dh, l) for l in range(depth + 1)]
+        P, r = self.plan, self.rank
+
+        def slab(l, kind, halo):
+            lo, hi = P.stored(l, kind, r, halo)
+            d = P.dims(l, kind)
+            return Slab(ops, lo, hi - lo, d[1], d[2])
+
+        def whole(l, kind):
+            d = P.dims(l, kind)
+            return Slab(ops, 0, d[0], d[1], d[2])
+
+        # distributed levels 0..cut-1 (phi/eps with a ping-pong twin), plus R and eps of level `cut`
+        self.phi, self.phi_alt = slab(0, "phi", self.H_U), slab(0, "phi", self.H_U)
+        self.b = slab(0, "R", self.H_RHS)
+        self.R = {l: slab(l, "R", self.H_RHS) for l in range(1, self.cut + 1)}
+        self.eps = {l: slab(l, "eps", self.H_U) for l in range(1, self.cut + 1)}
+        self.eps_alt = {l: slab(l, "eps", self.H_U) for l in range(1, self.cut)}
+        # gathered levels cut..depth, whole arrays, rank 0 only
+        self.cR, self.ceps, self.ceps_alt = {}, {}, {}
+        if r == 0:
+            for l in range(self.cut, depth + 1):
+                self.cR[l], self.ceps[l], self.ceps_alt[l] = whole(l, "R"), whole(l, "eps"), whole(l, "eps")
+        self.n_nodes = float(self.plan.n0[0]) * self.plan.n0[1] * self.plan.n0[2]
+        self.last_sum = None
+
+    # -- data in / out
+    def own(self, l, kind):
+        return self.plan.own(l, kind, self.rank)
+
+    def set_rho(self, rho_of_planes):
+        """rho_of_planes(lo, hi) -> dense array of global planes [lo,hi).  Stored as rho/EPS_0."""
+        lo, hi = self.plan.stored(0, "R", self.rank, self.H_RHS)
+        self.ops.upload(self.b, rho_of_planes(lo, hi), lo)
+        self.ops.div_eps0(self.b)
+
+    def set_phi(self, phi_of_planes):
+        lo, hi = self.plan.stored(0, "phi", self.rank, self.H_U)
+        self.ops.upload(self.phi, phi_of_planes(lo, hi), lo)
+
+    def get_phi_owned(self):
+        lo, hi = self.own(0, "phi")
+        return lo, self.phi.data(lo, hi)
+
+    # -- the cycle
+    def _sweeps(self, l):
+        """nu[l] red-black sweeps of a distributed level, one halo exchange after each."""
+        n = self.plan.level_n(l)
+        for _ in range(self.nu[l]):
+            if l == 0:
+                u, alt, rhs, own = self.phi, self.phi_alt, self.b, self.own(0, "phi")
+            else:
+                u, alt, rhs, own = self.eps[l], self.eps_alt[l], self.R[l], self.own(l, "eps")
+            if self.ops.smooth(u, alt, rhs, n, self.coef[l], self.omega, 1, own[0], own[1]):
+                if l == 0:
+                    self.phi, self.phi_alt = alt, u
+                else:
+                    self.eps[l], self.eps_alt[l] = alt, u
+                u = alt
+            self.comm.exchange(u, own, self.H_U)
+
+    def smooth_and_residual(self):
+        """Steps 1)-2b) of the reference iteration (+ the restriction to level 1, which shares the
+        pass).  Returns the global sum of squared residuals as a 1-element tensor."""
+        self._sweeps(0)
+        lo, hi = self.own(0, "phi")
+        s = self.ops.residual_restrict(self.phi, self.b, self.R[1], self.plan.n0, self.coef[0], lo, hi)
+        self.last_sum = self.comm.allreduce_sum(s)
+        return self.last_sum
+
+    def coarse_correction(self):
+        """Steps 3)-6): restrict down to the cut level, gather, solve the small levels on rank 0,
+        scatter, then (prolong, smooth) up and correct phi."""
+        P, ops, comm = self.plan, self.ops, self.comm
+        for l in range(1, self.cut):
+            # R_l's halo plane below feeds the restriction; both feed the sweeps' red halo planes
+            comm.exchange(self.R[l], self.own(l, "R"), self.H_RHS)
+            lo, hi = self.own(l + 1, "R")
+            ops.restrict27(self.R[l], self.R[l + 1], P.level_n(l), lo, hi)
+        comm.gather_planes(P, self.cut, "R", self.R[self.cut], self.cR.get(self.cut))
+        if self.rank == 0:
+            self._coarse_levels()
+        comm.scatter_planes(P, self.cut, "eps", self.ceps.get(self.cut), self.eps[self.cut], self.H_U)
+        for l in range(self.cut - 1, 0, -1):
+            lo, hi = self.own(l, "eps")
+            ops.prolong(self.eps[l + 1], self.eps[l], P.level_n(l), lo, hi, False)
+            comm.exchange(self.eps[l], (lo, hi), self.H_U)
+            self._sweeps(l)
+        # phi -= P(eps_1) on every stored plane, halos included: eps_1's halos are current
+        lo, hi = P.stored(0, "phi", self.rank, self.H_U)
+        ops.prolong(self.eps[1], self.phi, P.n0, lo, hi, True)
+
+    def _coarse_levels(self):
+        """Levels cut..depth on whole arrays (rank 0): restrict down, smooth the coarsest,
+        (prolong, smooth) back up to level `cut`."""
+        P, ops, L = self.plan, self.ops, self.depth
+        for l in range(self.cut, L):
+            ops.restrict27(self.cR[l], self.cR[l + 1], P.level_n(l), 0, P.planes(l + 1, "R"))
+        for l in range(L, self.cut - 1, -1):
+            if l < L:
+                ops.prolong(self.ceps[l + 1], self.ceps[l], P.level_n(l), 0, P.planes(l, "R"), False)
+            u, alt = self.ceps[l], self.ceps_alt[l]
+            if ops.smooth(u, alt, self.cR[l], P.level_n(l), self.coef[l], self.omega, self.nu[l], 0, u.planes):
+                self.ceps[l], self.ceps_alt[l] = alt, u
+
+    def l2(self, s=None):
+        s = self.last_sum if s is None else s
+        return math.sqrt(float(s.item()) / self.n_nodes)
+
+    def vcycles(self, count):
+        """`count` full iterations (no termination test); returns the last residual norm."""
+        for _ in range(count):
+            s = self.smooth_and_residual()
+            self.coarse_correction()
+        self.ops.sync()
+        return self.l2(s)
+
+    def solve(self, max_it=10000, tol=1e-4):
+        """The reference iteration loop: stop in the first iteration whose norm is < tol, before
+        that iteration's correction.  Returns (converged, residual evaluations, norm)."""
+        l2 = 0.0
+        for it in range(max_it):
+            l2 = self.l2(self.smooth_and_residual())
+            if l2 < tol:
+                return True, it + 1, l2
+            self.coarse_correction()
+        return False, max_it, l2

@@ -36,6 +36,12 @@ class MgTimers(C.Structure):
                 ("bytes", C.c_double * len(TIMER_KINDS))]
 
 
+class MgDevArray(C.Structure):
+    """mg_dev_array: planes [i0, i0+planes) of a level's array in device memory."""
+    _fields_ = [("ptr", C.c_void_p), ("planes", C.c_int64), ("nj", C.c_int64), ("nk", C.c_int64),
+                ("i0", C.c_int64)]
+
+
 class MgError(RuntimeError):
     def __init__(self, code, text):
         super().__init__(f"libmg_hip error {code}: {text}")
@@ -71,6 +77,21 @@ SYMBOLS = {
     "mg_op_prolong_correct": (C.c_int, [C.c_int, _i64x3, _dp, _dp]),
     "mg_op_smooth_rb": (C.c_int, [C.c_int, _i64x3, _i64x3, _i64x3, _f64x3, C.c_double, C.c_int, C.c_int, _dp, _dp]),
     "mg_op_sumsq": (C.c_int, [C.c_int, C.c_int64, _dp, _dp]),
+    # device-level operators of the slab-partitioned solve (multigrid_amd/dist.py)
+    "mg_dev_pitch": (C.c_int64, [C.c_int64]),
+    "mg_level_coef": (C.c_int, [_f64x3, C.c_int, C.c_double * 4]),
+    "mg_dev_div_eps0": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray)]),
+    "mg_dev_smooth_rb": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.POINTER(MgDevArray), C.POINTER(MgDevArray),
+                                   _i64x3, C.c_double * 4, C.c_double, C.c_int, C.c_int64, C.c_int64,
+                                   C.POINTER(C.c_int)]),
+    "mg_dev_residual_restrict": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.POINTER(MgDevArray),
+                                           C.POINTER(MgDevArray), _i64x3, C.c_double * 4, C.c_void_p, C.c_int64,
+                                           C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
+    "mg_dev_sum_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mg_dev_restrict27": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.POINTER(MgDevArray), _i64x3,
+                                    C.c_int64, C.c_int64]),
+    "mg_dev_prolong": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.POINTER(MgDevArray), _i64x3, C.c_int64,
+                                 C.c_int64, C.c_int]),
 }
 
 _lib = None

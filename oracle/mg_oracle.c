@@ -329,3 +329,156 @@ int orc_solve(orc_solver *s, double *phi, const double *rho, unsigned max_it,
     if (L2_out) *L2_out = L2;
     return converged;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Slab forms: the same loop nests on a SLAB of a level's global array -- planes
+ * [i0, i0+d[0]) stored with row pitch sj -- producing a range [lo, hi) of global
+ * planes.  They are the CPU twin of the device-level operators the slab-partitioned
+ * (multi-GPU) solve is built from, and reduce to the functions above for a slab
+ * that is the whole array.  The reference has no counterpart (it is a single
+ * process); what is restated is still its arithmetic, per point. */
+typedef struct {
+    double *p;
+    int64_t d[3];   /* stored planes, rows, columns */
+    int64_t si, sj; /* strides in doubles */
+    int64_t i0;     /* global index of stored plane 0 */
+} orc_view;
+
+#define VAT(v, i, j, k) ((v)->p[((i) - (v)->i0) * (v)->si + (j) * (v)->sj + (k)])
+
+/* One red-black sweep of planes [lo,hi): red (colour 0) also on planes lo-1 and hi where
+ * their neighbours are stored, then black on [lo,hi); updates stay within 1..n-2. */
+void orc_slab_smooth_rb(orc_view *u, const orc_view *rhs, const int64_t n[3], const double c[4],
+                        double omega, int64_t lo, int64_t hi)
+{
+    for (int colour = 0; colour < 2; colour++) {
+        int64_t a = colour == 0 ? lo - 1 : lo, b = colour == 0 ? hi + 1 : hi;
+        if (colour == 0) {
+            if (a < u->i0 + 1) a = u->i0 + 1;
+            if (b > u->i0 + u->d[0] - 1) b = u->i0 + u->d[0] - 1;
+        }
+        if (a < 1) a = 1;
+        if (b > n[0] - 1) b = n[0] - 1;
+        for (int64_t i = a; i < b; i++)
+            for (int64_t j = 1; j < n[1] - 1; j++)
+                for (int64_t k = 1 + ((i + j + 1 + colour) & 1); k < n[2] - 1; k += 2) {
+                    double g = (VAT(rhs, i, j, k) + c[0] * (VAT(u, i - 1, j, k) + VAT(u, i + 1, j, k)) +
+                                c[1] * (VAT(u, i, j - 1, k) + VAT(u, i, j + 1, k)) +
+                                c[2] * (VAT(u, i, j, k - 1) + VAT(u, i, j, k + 1))) / c[3];
+                    VAT(u, i, j, k) = VAT(u, i, j, k) + omega * (g - VAT(u, i, j, k));
+                }
+    }
+}
+
+static double slab_residual_at(const orc_view *phi, const orc_view *b, const int64_t n[3],
+                               const double c[4], int64_t i, int64_t j, int64_t k)
+{
+    if (i == 0 || i == n[0] - 1 || j == 0 || j == n[1] - 1 || k == 0 || k == n[2] - 1)
+        return VAT(phi, i, j, k) - 0;
+    return VAT(phi, i, j, k) * c[3] - VAT(b, i, j, k) -
+           c[0] * (VAT(phi, i - 1, j, k) + VAT(phi, i + 1, j, k)) -
+           c[1] * (VAT(phi, i, j - 1, k) + VAT(phi, i, j + 1, k)) -
+           c[2] * (VAT(phi, i, j, k - 1) + VAT(phi, i, j, k + 1));
+}
+
+/* Coarse planes I with lo <= 2I < hi of Rc = restrict27(residual(phi, b)); b = rho/EPS_0.
+ * Returns the sum of squares of the fine residual over planes [lo,hi), i,j,k order. */
+double orc_slab_residual_restrict(const orc_view *phi, const orc_view *b, orc_view *Rc,
+                                  const int64_t n[3], const double c[4], int64_t lo, int64_t hi)
+{
+    static const double w1[3] = {1, 2, 1};
+    double sum = 0;
+    for (int64_t i = lo; i < hi; i++)
+        for (int64_t j = 0; j < n[1]; j++)
+            for (int64_t k = 0; k < n[2]; k++) {
+                double r = slab_residual_at(phi, b, n, c, i, j, k);
+                sum += r * r;
+            }
+    for (int64_t i = lo; i < hi && i < n[0] - 1; i += 2)
+        for (int64_t j = 0; j < n[1] - 1; j += 2)
+            for (int64_t k = 0; k < n[2] - 1; k += 2) {
+                double v;
+                if (i == 0 || j == 0 || k == 0) {
+                    v = slab_residual_at(phi, b, n, c, i, j, k);
+                } else {
+                    int first = 1;
+                    v = 0;
+                    for (int dk = -1; dk <= 1; dk++)
+                        for (int dj = -1; dj <= 1; dj++)
+                            for (int di = -1; di <= 1; di++) {
+                                double w = w1[di + 1] * w1[dj + 1] * w1[dk + 1];
+                                double r = slab_residual_at(phi, b, n, c, i + di, j + dj, k + dk);
+                                double t = (w == 1.0) ? r : w * r;
+                                if (first) { v = t; first = 0; } else v = v + t;
+                            }
+                    v = v / 64.0;
+                }
+                VAT(Rc, i / 2, j / 2, k / 2) = v;
+            }
+    return sum;
+}
+
+/* Coarse planes [lo,hi) of Rc = restrict27(Rf); nf = fine level size. */
+void orc_slab_restrict27(const orc_view *Rf, orc_view *Rc, const int64_t nf[3], int64_t lo, int64_t hi)
+{
+    static const double w1[3] = {1, 2, 1};
+    for (int64_t I = lo; I < hi; I++) {
+        const int64_t i = 2 * I;
+        if (i >= nf[0] - 1) break;
+        for (int64_t j = 0; j < nf[1] - 1; j += 2)
+            for (int64_t k = 0; k < nf[2] - 1; k += 2) {
+                double v;
+                if (i == 0 || j == 0 || k == 0) {
+                    v = VAT(Rf, i, j, k);
+                } else {
+                    int first = 1;
+                    v = 0;
+                    for (int dk = -1; dk <= 1; dk++)
+                        for (int dj = -1; dj <= 1; dj++)
+                            for (int di = -1; di <= 1; di++) {
+                                double w = w1[di + 1] * w1[dj + 1] * w1[dk + 1];
+                                double r = VAT(Rf, i + di, j + dj, k + dk);
+                                double t = (w == 1.0) ? r : w * r;
+                                if (first) { v = t; first = 0; } else v = v + t;
+                            }
+                    v = v / 64.0;
+                }
+                VAT(Rc, I, j / 2, k / 2) = v;
+            }
+    }
+}
+
+/* Fine planes [lo,hi) within 0..n-2: out = P(ec), or out -= P(ec) when correct. */
+void orc_slab_prolong(const orc_view *ec, orc_view *out, const int64_t n[3], int64_t lo, int64_t hi,
+                      int correct)
+{
+#define C(a, b, d) VAT(ec, I + (a), J + (b), K + (d))
+    for (int64_t i = lo; i < hi && i < n[0] - 1; i++)
+        for (int64_t j = 0; j < n[1] - 1; j++)
+            for (int64_t k = 0; k < n[2] - 1; k++) {
+                const int64_t I = i / 2, J = j / 2, K = k / 2;
+                const int oi = (int)(i & 1), oj = (int)(j & 1), ok = (int)(k & 1);
+                double v;
+                if (i == 0 || j == 0 || k == 0) v = 0;
+                else if (!oi && !oj && !ok) v = C(0, 0, 0);
+                else if (oi && !oj && !ok) v = 0.5 * (C(0, 0, 0) + C(1, 0, 0));
+                else if (!oi && oj && !ok) v = 0.5 * (C(0, 0, 0) + C(0, 1, 0));
+                else if (!oi && !oj && ok) v = 0.5 * (C(0, 0, 0) + C(0, 0, 1));
+                else if (oi && oj && !ok) v = 0.25 * (C(0, 0, 0) + C(1, 0, 0) + C(0, 1, 0) + C(1, 1, 0));
+                else if (oi && !oj && ok) v = 0.25 * (C(0, 0, 0) + C(1, 0, 0) + C(0, 0, 1) + C(1, 0, 1));
+                else if (!oi && oj && ok) v = 0.25 * (C(0, 0, 0) + C(0, 1, 0) + C(0, 0, 1) + C(0, 1, 1));
+                else v = 0.125 * (C(0, 0, 0) + C(1, 0, 0) + C(0, 1, 0) + C(1, 1, 0) +
+                                  C(0, 0, 1) + C(1, 0, 1) + C(0, 1, 1) + C(1, 1, 1));
+                if (correct) VAT(out, i, j, k) = VAT(out, i, j, k) - v;
+                else VAT(out, i, j, k) = v;
+            }
+#undef C
+}
+
+/* v /= EPS_0 over the stored slab (rows of d[2] nodes). */
+void orc_slab_div_eps0(orc_view *v)
+{
+    for (int64_t i = 0; i < v->d[0]; i++)
+        for (int64_t j = 0; j < v->d[1]; j++)
+            for (int64_t k = 0; k < v->d[2]; k++) v->p[i * v->si + j * v->sj + k] /= ORC_EPS_0;
+}

@@ -33,6 +33,23 @@ def build(force=False):
     return _SO
 
 
+class OrcView(C.Structure):
+    """orc_view: planes [i0, i0+d[0]) of a level's array, row pitch sj."""
+    _fields_ = [("p", _dp), ("d", C.c_int64 * 3), ("si", C.c_int64), ("sj", C.c_int64), ("i0", C.c_int64)]
+
+
+def view(a, nk, i0):
+    """orc_view of a C-contiguous float64 array a[planes][nj][pitch] holding rows of nk nodes."""
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.ndim == 3
+    v = OrcView()
+    v.p = a.ctypes.data_as(_dp)
+    v.d[0], v.d[1], v.d[2] = a.shape[0], a.shape[1], nk
+    v.sj = a.shape[2]
+    v.si = a.shape[1] * a.shape[2]
+    v.i0 = i0
+    return v
+
+
 _lib = None
 
 
@@ -74,6 +91,17 @@ def lib():
         L.orc_solve.argtypes = [C.c_void_p, _dp, _dp, C.c_uint, C.c_double, C.c_int,
                                 C.POINTER(C.c_uint), _dp, _dp]
         L.orc_solve.restype = C.c_int
+        V = C.POINTER(OrcView)
+        L.orc_slab_smooth_rb.argtypes = [V, V, _i64x3, _f64x4, C.c_double, C.c_int64, C.c_int64]
+        L.orc_slab_smooth_rb.restype = None
+        L.orc_slab_residual_restrict.argtypes = [V, V, V, _i64x3, _f64x4, C.c_int64, C.c_int64]
+        L.orc_slab_residual_restrict.restype = C.c_double
+        L.orc_slab_restrict27.argtypes = [V, V, _i64x3, C.c_int64, C.c_int64]
+        L.orc_slab_restrict27.restype = None
+        L.orc_slab_prolong.argtypes = [V, V, _i64x3, C.c_int64, C.c_int64, C.c_int]
+        L.orc_slab_prolong.restype = None
+        L.orc_slab_div_eps0.argtypes = [V]
+        L.orc_slab_div_eps0.restype = None
         _lib = L
     return _lib
 

@@ -1,0 +1,133 @@
+"""The slab-partitioned solve on CPU: the product's orchestration (multigrid_amd/dist.py: plan,
+halo exchange schedule, coarse gather/scatter, all-reduce) runs over gloo with world_size 2 and 3,
+with the oracle's slab-form operators standing in for the GPU kernels, and must reproduce the
+undivided red-black oracle bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import assert_bit_equal
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, depth, cut, cycles, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multigrid_amd import dist as mgd, problem
+        from oracle_ops import OracleOps
+        N = (n, n, n)
+        s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, OracleOps(), mgd.Comm(), cut=cut)
+        s.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
+        s.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
+        hist = [s.vcycles(1) for _ in range(cycles)]
+        lo, phi = s.get_phi_owned()
+        np.save(os.path.join(out_dir, f"phi_{rank}.npy"), phi)
+        np.save(os.path.join(out_dir, f"lo_{rank}.npy"), np.array([lo]))
+        if rank == 0:
+            np.save(os.path.join(out_dir, "hist.npy"), np.array(hist))
+        # the solve loop: all ranks must agree on the stopping iteration
+        s2 = mgd.DistSolver(N, problem.main_extents_dh(N), depth, OracleOps(), mgd.Comm(), cut=cut)
+        s2.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
+        s2.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
+        ok, cyc, l2 = s2.solve(200, 1e-2)
+        np.save(os.path.join(out_dir, f"solve_{rank}.npy"), np.array([float(ok), cyc, l2]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,depth,cut", [(2, 33, 2, 1), (2, 33, 3, 2), (3, 65, 3, 2), (2, 41, 2, 2)])
+def test_partitioned_cycle_equals_undivided_oracle(orc, tmp_path, world, n, depth, cut):
+    cycles = 3
+    mp.spawn(_worker, args=(world, free_port(), n, depth, cut, cycles, str(tmp_path)), nprocs=world, join=True)
+    N = (n, n, n)
+    dh = orc.main_extents_dh(N)
+    rho = orc.synthetic_rho(N)
+    want = np.zeros(N)
+    ok, cyc, l2, hist = orc.Solver(N, dh, depth).solve(want, rho, cycles, 0.0, rb=True)
+    got = np.zeros(N)
+    for r in range(world):
+        lo = int(np.load(tmp_path / f"lo_{r}.npy")[0])
+        part = np.load(tmp_path / f"phi_{r}.npy")
+        got[lo:lo + part.shape[0]] = part
+    assert_bit_equal(got, want, "phi assembled from the slabs")
+    assert np.load(tmp_path / "hist.npy") == pytest.approx(hist, rel=1e-12)
+    # solve(): same stopping iteration as the undivided red-black oracle, on every rank
+    ref = np.zeros(N)
+    ok, cyc, l2, _ = orc.Solver(N, dh, depth).solve(ref, rho, 200, 1e-2, rb=True)
+    for r in range(world):
+        s = np.load(tmp_path / f"solve_{r}.npy")
+        assert (bool(s[0]), int(s[1])) == (ok, cyc)
+        assert s[2] == pytest.approx(l2, rel=1e-12)
+
+
+def test_plan_partitions_every_level(mg):
+    from multigrid_amd.dist import SlabPlan
+    for n0, depth, world in [(1025, 6, 8), (1025, 6, 2), (513, 5, 4), (2049, 7, 8), (129, 3, 2)]:
+        p = SlabPlan((n0,) * 3, depth, world)
+        assert 1 <= p.cut <= depth
+        for l in range(p.cut + 1):
+            for kind in ("R", "eps"):
+                covered = []
+                for r in range(world):
+                    lo, hi = p.own(l, kind, r)
+                    assert lo < hi
+                    covered += list(range(lo, hi))
+                    if r < world - 1:  # coarse slabs nest: boundaries halve exactly
+                        assert (p.bounds[r + 1] >> l) << l == p.bounds[r + 1]
+                assert covered == list(range(p.planes(l, kind)))
+        # residual+restrict needs even slab starts on the fine level
+        assert all(b % 2 == 0 for b in p.bounds[:-1])
+
+
+def test_plan_rejects_impossible_partitions(mg):
+    from multigrid_amd.dist import SlabPlan
+    with pytest.raises(ValueError):
+        SlabPlan((33, 33, 33), 3, 8, cut=3)   # fewer than 2^cut planes per rank
+    with pytest.raises(ValueError):
+        SlabPlan((33, 33, 33), 2, 2, cut=3)   # cut below the coarsest level
+
+
+def test_slab_forms_reduce_to_whole_array_forms(orc):
+    """The oracle's slab-form operators on a whole-array 'slab' equal its original operators."""
+    import ctypes as C
+    from util import phi_like, rng
+    g = rng(21)
+    n = (17, 13, 15)
+    c = orc.coeffs((0.01, 0.02, 0.03), 0)
+    phi, rho = phi_like(n, g), phi_like(n, g) * orc.EPS_0
+    # residual + restrict
+    R, s = orc.residual(phi, rho, c)
+    Rc = orc.restrict27(R)
+    b = rho / orc.EPS_0
+    got_Rc = np.zeros_like(Rc)
+    got_s = orc.lib().orc_slab_residual_restrict(C.byref(orc.view(phi, n[2], 0)), C.byref(orc.view(b, n[2], 0)),
+                                                 C.byref(orc.view(got_Rc, Rc.shape[2], 0)), (C.c_int64 * 3)(*n),
+                                                 (C.c_double * 4)(*c), 0, n[0])
+    assert_bit_equal(got_Rc, Rc, "slab residual+restrict")
+    assert got_s == s
+    # smoother (coarse form: u one node larger than rhs)
+    u = phi_like(tuple(a + 1 for a in n), g)
+    want = orc.smooth(u.copy(), R, n, c, 1.4, 1, rb=True)
+    got = u.copy()
+    orc.lib().orc_slab_smooth_rb(C.byref(orc.view(got, n[2] + 1, 0)), C.byref(orc.view(R, n[2], 0)),
+                                 (C.c_int64 * 3)(*n), (C.c_double * 4)(*c), 1.4, 0, n[0] + 1)
+    assert_bit_equal(got, want, "slab smoother")
+    # prolongation
+    ec = phi_like(tuple((a >> 1) + 1 for a in n), g)
+    want = orc.prolong(ec, phi.copy(), n)
+    got = phi.copy()
+    orc.lib().orc_slab_prolong(C.byref(orc.view(ec, ec.shape[2], 0)), C.byref(orc.view(got, n[2], 0)),
+                               (C.c_int64 * 3)(*n), 0, n[0], 0)
+    assert_bit_equal(got, want, "slab prolong")
