@@ -7,7 +7,10 @@ A step is one full V-cycle iteration (smooth, residual + norm, restrict, coarse
 levels, prolong + correct) on the synthetic charge density of
 multigrid_amd/problem.py, with phi and rho resident in HBM before the timed
 region.  N = 1 runs the 513^3 five-level cycle (the configuration the headline
-metric is quoted on).  Rank 0 prints ONE JSON line.
+metric is quoted on); N > 1 (one rank per GPU under torch.distributed.run) runs
+1025^3 slab-partitioned.  `value` is GDoF/s = fine-grid unknowns x V-cycles/s /
+1e9, comparable across grid sizes; V-cycles/s is reported beside it.  Rank 0
+prints ONE JSON line.
 
 Besides the contract fields the line carries:
   roofline      the dominant kernel's algorithmic bytes / its HIP-event time, vs 8 TB/s
@@ -42,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-cycles", type=int, default=3, help="cycles of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-solve", action="store_true", help="skip the time-to-1e-6 solve")
     ap.add_argument("--tol", type=float, default=1e-6)
+    ap.add_argument("--no-single-gpu-compare", action="store_true",
+                    help="N>1: skip timing the same workload on one GPU of the node")
     return ap.parse_args()
 
 
@@ -124,25 +129,141 @@ def run_single(args):
 
     cpu = cpu_baseline(n, depth, args.cpu_cycles) if args.cpu_cycles > 0 else None
 
-    out = {"metric": "V-cycles/s", "value": vps, "unit": "V-cycles/s", "n_gpus": 1, "steps": args.steps,
+    out = {"metric": "GDoF/s", "value": npts * vps / 1e9, "unit": "GDoF/s (fine-grid unknowns x V-cycles/s / 1e9)",
+           "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"{n}^3 fp64 multigrid V{depth} cycle (sweeps {list(h.cfg.nu[:depth + 1])}, omega 1.4), "
                                   f"red-black GS-SOR, 1 GPU", "grid": n, "depth": depth},
-           "gdof_per_s": npts * vps / 1e9, "device_ms_per_step": dev_ms / args.steps, "last_L2": l2,
+           "vcycles_per_s": vps, "device_ms_per_step": dev_ms / args.steps, "last_L2": l2,
            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "solve": solve}
     if cpu:
         out["speedup_vs_cpu_per_cycle"] = cpu["s_per_cycle"] / (wall / args.steps)
     print(json.dumps(out))
 
 
+def run_distributed(args):
+    """N > 1: one rank per GPU (launched by torch.distributed.run), 1025^3 slab-partitioned."""
+    import torch  # before libmg_hip: both must share one HIP runtime
+    import torch.distributed as dist
+    import numpy as np
+    from multigrid_amd import dist as mgd, problem
+
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    world = int(os.environ["WORLD_SIZE"])
+    # RCCL prints a version banner on stdout at communicator creation; keep stdout for the one
+    # JSON line by pointing fd 1 at stderr until the result is ready
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    n = args.size or 1025
+    N = (n, n, n)
+    depth = args.depth or problem.reference_depth_for(N)
+    dh = problem.main_extents_dh(N)
+    ops = mgd.HipOps(local)
+    comm = mgd.Comm()
+    s = mgd.DistSolver(N, dh, depth, ops, comm)
+    s.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
+    s.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup:
+        s.vcycles(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    l2 = s.vcycles(args.steps)
+    fence()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    wall = float(dt.item())
+    vps = args.steps / wall
+    npts = float(n) ** 3
+
+    # dominant kernel: the fused red-black sweep on this rank's fine slab, HIP events on the launch stream
+    lo, hi = s.own(0, "phi")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    reps = 5
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(reps):
+        ops.smooth(s.phi, s.phi_alt, s.b, N, s.coef[0], s.omega, 1, lo, hi)  # result discarded: timing only
+    ev[1].record()
+    torch.cuda.synchronize()
+    sweep_us = ev[0].elapsed_time(ev[1]) * 1e3 / reps
+    sweep_bytes = 32.0 * (hi - lo) * n * n
+    roofline = {"bound": "hbm", "kernel": "smooth_fine (one full red-black sweep of this rank's slab)",
+                "achieved": sweep_bytes / (sweep_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": sweep_bytes / (sweep_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "avg_us": sweep_us, "bytes_per_launch": sweep_bytes}
+
+    solve = None
+    if not args.no_solve:
+        s2 = mgd.DistSolver(N, dh, depth, ops, comm)
+        s2.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
+        s2.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
+        fence()
+        t0 = time.perf_counter()
+        ok, cycles, l2s = s2.solve(10000, args.tol)
+        fence()
+        solve = {"tol": args.tol, "converged": ok, "cycles": cycles, "seconds": time.perf_counter() - t0, "L2": l2s}
+        del s2
+
+    base1 = None
+    if rank == 0 and not args.no_single_gpu_compare:
+        from multigrid_amd import libmg
+        del s
+        torch.cuda.empty_cache()
+        h = libmg.Handle(N, dh, depth, device=local)
+        h.set_rho(problem.synthetic_rho(N))
+        h.set_phi(np.zeros(N))
+        h.vcycles(2)
+        t0 = time.perf_counter()
+        k = max(3, min(args.steps, 10))
+        h.vcycles(k)
+        t1 = (time.perf_counter() - t0) / k
+        h.close()
+        base1 = {"workload": f"{n}^3 V{depth} on one GPU of this node, same run", "ms_per_step": t1 * 1e3,
+                 "vcycles_per_s": 1.0 / t1, "gdof_per_s": npts / t1 / 1e9, "speedup": vps * t1}
+    dist.barrier()
+    if rank == 0:
+        out = {"metric": "GDoF/s", "value": npts * vps / 1e9, "unit": "GDoF/s (fine-grid unknowns x V-cycles/s / 1e9)",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"{n}^3 fp64 multigrid V{depth} cycle, red-black GS-SOR, slab-partitioned over "
+                                      f"{world} GPUs (halo planes over RCCL send/recv, levels >= {s_cut(N, depth, world)} "
+                                      f"gathered on rank 0)", "grid": n, "depth": depth,
+                          "note": "N=1 runs the 513^3 headline configuration; N>=2 run 1025^3 (strong scaling among N>=2)"},
+               "vcycles_per_s": vps, "last_L2": l2, "roofline": roofline, "cpu_baseline": None, "solve": solve,
+               "single_gpu_same_workload": base1, "halo_bytes_sent_rank0": comm.bytes_sent}
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    dist.destroy_process_group()
+
+
+def s_cut(N, depth, world):
+    from multigrid_amd.dist import SlabPlan
+    return SlabPlan(N, depth, world).cut
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus == 1 and world == 1:
+    if args.gpus == 1 and world == 1 and not os.environ.get("MG_BENCH_FORCE_DIST"):
         run_single(args)
         return
-    raise SystemExit("bench.py: the multi-GPU (slab-partitioned) path is not implemented yet")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs one process per GPU: launch with "
+                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
+    run_distributed(args)
 
 
 if __name__ == "__main__":
