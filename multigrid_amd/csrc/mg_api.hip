@@ -55,12 +55,7 @@ Coef level_coef(const double dh[3], int level)
     for (int l = 0; l < level; l++) f *= 4.0;
     double c[3];
     for (int a = 0; a < 3; a++) c[a] = (level == 0) ? 1.0 / (dh[a] * dh[a]) : 1.0 / (f * dh[a] * dh[a]);
-    Coef r;
-    r.cx = c[0];
-    r.cy = c[1];
-    r.cz = c[2];
-    r.d = 2 * c[0] + 2 * c[1] + 2 * c[2];
-    return r;
+    return mgk::make_coef(c[0], c[1], c[2], 2 * c[0] + 2 * c[1] + 2 * c[2]);
 }
 
 View make_view(double *p, const int64_t d[3])
@@ -753,11 +748,7 @@ int mg_op_smooth_rb(int device, const int64_t n[3], const int64_t u_dims[3], con
     TRY(sc.view(&valt, u_dims, nullptr));
     TRY(sc.view(&vr, rhs_dims, rhs));
     if (rhs_is_rho) mgk::div_eps0(nullptr, vr);
-    Coef k;
-    k.cx = c[0];
-    k.cy = c[1];
-    k.cz = c[2];
-    k.d = 2 * c[0] + 2 * c[1] + 2 * c[2];
+    const Coef k = mgk::make_coef(c[0], c[1], c[2], 2 * c[0] + 2 * c[1] + 2 * c[2]);
     mgk::smooth_rb(nullptr, &vu, &valt, vr, n, k, omega, sweeps, IRange{0, u_dims[0]});
     HIP_TRY(hipGetLastError());
     return sc.download(vu, u);
@@ -811,15 +802,7 @@ int need_planes(const View &v, int64_t lo, int64_t hi, int64_t gmax, const char 
     return MG_OK;
 }
 
-Coef coef4(const double c[4])
-{
-    Coef k;
-    k.cx = c[0];
-    k.cy = c[1];
-    k.cz = c[2];
-    k.d = c[3];
-    return k;
-}
+Coef coef4(const double c[4]) { return mgk::make_coef(c[0], c[1], c[2], c[3]); }
 
 }  // namespace
 

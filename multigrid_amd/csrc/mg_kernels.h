@@ -31,7 +31,31 @@ struct IRange { int64_t lo, hi; };  // global planes [lo, hi)
 // Row pitch used for every device array: rows start 16-byte aligned.
 inline int64_t pitch_for(int64_t nk) { return (nk + 1) & ~int64_t(1); }
 
-struct Coef { double cx, cy, cz, d; };
+// Stencil coefficients of a level: 1/h^2 per axis, d = 2cx+2cy+2cz, and what div_d() needs.
+struct Coef {
+    double cx, cy, cz, d;
+    double rd;     // 1.0/d, correctly rounded
+    int fma_div;   // 1: div_d() may use the reciprocal form (see div_d)
+};
+// Fills rd / fma_div from d.
+Coef make_coef(double cx, double cy, double cz, double d);
+
+#if defined(__HIPCC__)
+// x / c.d, correctly rounded (bit-identical to the IEEE division the reference performs,
+// cpp/PotentialSolver.cpp:3783), from the correctly rounded reciprocal rd instead of the
+// ~15-instruction division sequence.  q1 = fma(x - q0*d, rd, q0) is within half an ulp (plus
+// second-order terms) of x/d, hence a faithful rounding; its residual r1 = x - q1*d is then exact
+// in one FMA, and Markstein's theorem (the reciprocal is correctly rounded, the significand of d
+// is not all ones -- checked on the host) makes fma(r1, rd, q1) the correctly rounded quotient.
+// Explicit fma() calls are not contractions: -ffp-contract=off does not affect them.
+__device__ __forceinline__ double div_d(double x, const Coef &c)
+{
+    if (!c.fma_div) return x / c.d;
+    const double q0 = x * c.rd;
+    const double q1 = fma(fma(-q0, c.d, x), c.rd, q0);
+    return fma(fma(-q1, c.d, x), c.rd, q1);
+}
+#endif
 
 // v = v / EPS_0 in place over the whole view: turns an uploaded rho into the rhs b.
 void div_eps0(hipStream_t s, View v);

@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void k_smooth_colour(View u, View rhs, int64_t
     if (j > nj - 2 || k > nk - 2) return;
     double *p = u.p + u.at(i, j, k);
     const double b = rhs.p[rhs.at(i, j, k)];
-    const double g = (b + c.cx * (p[-u.si] + p[u.si]) + c.cy * (p[-u.sj] + p[u.sj]) +
-                      c.cz * (p[-1] + p[1])) / c.d;
+    const double g = div_d(b + c.cx * (p[-u.si] + p[u.si]) + c.cy * (p[-u.sj] + p[u.sj]) +
+                           c.cz * (p[-1] + p[1]), c);
     const double u0 = p[0];
     p[0] = u0 + omega * (g - u0);
 }
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(1024) void k_smooth_lds(View u, View rhs, int nI, i
                 const int k = 1 + ((i + j + 1 + colour) & 1) + 2 * m;
                 if (k <= nK - 2) {
                     double *p = su + i * si + j * sj + k;
-                    const double g = (sr[(i * rJ + j) * rK + k] + c.cx * (p[-si] + p[si]) +
-                                      c.cy * (p[-sj] + p[sj]) + c.cz * (p[-1] + p[1])) / c.d;
+                    const double g = div_d(sr[(i * rJ + j) * rK + k] + c.cx * (p[-si] + p[si]) +
+                                           c.cy * (p[-sj] + p[sj]) + c.cz * (p[-1] + p[1]), c);
                     const double u0 = p[0];
                     p[0] = u0 + omega * (g - u0);
                 }
@@ -264,6 +264,29 @@ __global__ __launch_bounds__(256) void k_correct(double *__restrict__ phi,
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < count; p += stride)
         phi[p] = phi[p] - eps[p];
 }
+
+}  // namespace
+
+Coef make_coef(double cx, double cy, double cz, double d)
+{
+    Coef c;
+    c.cx = cx;
+    c.cy = cy;
+    c.cz = cz;
+    c.d = d;
+    c.rd = 1.0 / d;
+    // the reciprocal form needs a normal, finite d whose significand is not all ones, and a
+    // quotient range far from overflow/underflow (always true for mesh coefficients)
+    uint64_t bits;
+    memcpy(&bits, &d, sizeof(bits));
+    const uint64_t frac = bits & 0xFFFFFFFFFFFFFull;
+    const int expo = (int)((bits >> 52) & 0x7FF);
+    static const bool exact_div = getenv("MG_EXACT_DIV") != nullptr;  // A/B: force true division
+    c.fma_div = (!exact_div && d > 0 && expo > 100 && expo < 1900 && frac != 0xFFFFFFFFFFFFFull) ? 1 : 0;
+    return c;
+}
+
+namespace {
 
 inline dim3 grid_for(int64_t nk, int64_t nj, int64_t ni)
 {

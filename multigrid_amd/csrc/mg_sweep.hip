@@ -42,23 +42,36 @@ __device__ __forceinline__ d2 put(d2 v, int e, double x)
 // WJ rows x 2*WKP columns per window; outputs are the window minus two rings.
 // D = planes of u (and of the right-hand side) requested ahead of use: the march is
 // latency bound unless several planes per workgroup are in flight.
-template <int WJ, int WKP, int D>
-__global__ __launch_bounds__(256) void k_sweep_rb(View uin, View uout, View rhs, int nI, int nJ,
+template <int WJ, int WKP, int D, int NT>
+__global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, int nI, int nJ,
                                                   int nK, Coef c, double omega, int CI, int nchunks,
-                                                  int tiles_k, int rlo, int rhi)
+                                                  int tiles_k, int rlo, int rhi, int xcd_map)
 {
     constexpr int WK = 2 * WKP;
     constexpr int TJ = WJ - 4, TK = WK - 4;
-    constexpr int RPP = 256 / WKP;  // rows covered by one pass of the workgroup
+    constexpr int RPP = NT / WKP;   // rows covered by one pass of the workgroup
     constexpr int Q = WJ / RPP;     // pair-columns owned by a thread
     static_assert(WJ % RPP == 0, "window rows must be a multiple of rows per pass");
     __shared__ double lds[3][WJ][WK];
 
     const int tid = threadIdx.x;
     const int m = tid % WKP, rr = tid / WKP;
-    // chunk index fastest: workgroups of one i-chunk share blockIdx % 8, i.e. an XCD and its L2
-    const int chunk = blockIdx.x % nchunks;
-    const int tile = blockIdx.x / nchunks;
+    // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 labels the XCD).  Remap so that
+    // each XCD works on a contiguous run of (chunk, tile) items: windows that share halo columns and
+    // rows then run on one XCD at about the same time, and the second fetch of a halo line hits
+    // that XCD's L2.  Speed only: any mapping gives the same result.
+    int chunk, tile;
+    if (xcd_map) {
+        const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7;
+        const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int w = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + idx;
+        const int ntiles = nwg / nchunks;
+        chunk = w / ntiles;
+        tile = w % ntiles;
+    } else {
+        chunk = blockIdx.x % nchunks;
+        tile = blockIdx.x / nchunks;
+    }
     const int tk = tile % tiles_k, tj = tile / tiles_k;
     const int j0 = tj * TJ - 2, k0 = tk * TK - 2;
     const int uJ = (int)uin.d[1], uK = (int)uin.d[2];
@@ -129,8 +142,8 @@ __global__ __launch_bounds__(256) void k_sweep_rb(View uin, View uout, View rhs,
                 const int rn = max(r - 1, 0), rs = min(r + 1, WJ - 1);
                 const int cw = max(col - 1, 0), ce = min(col + 1, WK - 1);
                 const double uc = pick(v0[q], e);
-                const double g = (pick(b0[q], e) + c.cx * (pick(vm1[q], e) + pick(vp1[q], e)) +
-                                  c.cy * (X[rn][col] + X[rs][col]) + c.cz * (X[r][cw] + X[r][ce])) / c.d;
+                const double g = div_d(pick(b0[q], e) + c.cx * (pick(vm1[q], e) + pick(vp1[q], e)) +
+                                       c.cy * (X[rn][col] + X[rs][col]) + c.cz * (X[r][cw] + X[r][ce]), c);
                 const double un = ok ? uc + omega * (g - uc) : uc;
                 v0[q] = put(v0[q], e, un);
                 X[r][col] = un;
@@ -154,8 +167,8 @@ __global__ __launch_bounds__(256) void k_sweep_rb(View uin, View uout, View rhs,
                     const int rn = max(r - 1, 0), rs = min(r + 1, WJ - 1);
                     const int cw = max(col - 1, 0), ce = min(col + 1, WK - 1);
                     const double uc = pick(vm1[q], e);
-                    const double g = (pick(bm1[q], e) + c.cx * (pick(vm2[q], e) + pick(v0[q], e)) +
-                                      c.cy * (Y[rn][col] + Y[rs][col]) + c.cz * (Y[r][cw] + Y[r][ce])) / c.d;
+                    const double g = div_d(pick(bm1[q], e) + c.cx * (pick(vm2[q], e) + pick(v0[q], e)) +
+                                           c.cy * (Y[rn][col] + Y[rs][col]) + c.cz * (Y[r][cw] + Y[r][ce]), c);
                     vm1[q] = put(vm1[q], e, ok ? uc + omega * (g - uc) : uc);
                 }
             }
@@ -208,20 +221,37 @@ void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t 
     if (planes <= 0) return;
     const int tiles_j = (int)((uin.d[1] + TJ - 1) / TJ);
     const int tiles_k = (int)((uin.d[2] + TK - 1) / TK);
-    // i-chunks: a multiple of 8 (one group per XCD) and enough workgroups to fill 256 CUs
-    int nchunks = 8;
-    while ((int64_t)nchunks * tiles_j * tiles_k < 1024 && planes / (nchunks * 2) >= 8) nchunks *= 2;
-    if (planes < 16) nchunks = 1;
+    static const int xcd_map = env_int("MG_SWEEP_MAP", 0);
+    const int tiles = tiles_j * tiles_k;
+    int nchunks;
+    if (xcd_map) {
+        // one cohort: about two workgroups per CU resident at once, all started together
+        nchunks = (int)((512 + tiles / 2) / tiles);
+        if (nchunks < 1) nchunks = 1;
+        while (nchunks > 1 && planes / nchunks < 8) nchunks--;
+    } else {
+        // i-chunks: a multiple of 8 (one group per XCD) and enough workgroups to fill 256 CUs
+        nchunks = 8;
+        while ((int64_t)nchunks * tiles < 1024 && planes / (nchunks * 2) >= 8) nchunks *= 2;
+        if (planes < 16) nchunks = 1;
+    }
     if (want_chunks > 0) nchunks = want_chunks;
     const int CI = (int)((planes + nchunks - 1) / nchunks);
-    const unsigned grid = (unsigned)(nchunks * tiles_j * tiles_k);
-#define LAUNCH(D)                                                                                  \
-    hipLaunchKernelGGL((k_sweep_rb<WJ, WKP, D>), dim3(grid), dim3(256), 0, s, uin, uout, rhs,      \
+    const unsigned grid = (unsigned)(nchunks * tiles);
+    static const int threads = env_int("MG_SWEEP_NT", 256);
+#define LAUNCH(D, NT)                                                                              \
+    hipLaunchKernelGGL((k_sweep_rb<WJ, WKP, D, NT>), dim3(grid), dim3(NT), 0, s, uin, uout, rhs,   \
                        (int)n[0], (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k, (int)r.lo, \
-                       (int)r.hi)
-    if (depth <= 1) LAUNCH(1);
-    else if (depth == 2) LAUNCH(2);
-    else LAUNCH(3);
+                       (int)r.hi, xcd_map)
+    if (threads == 512) {
+        if (depth <= 1) LAUNCH(1, 512);
+        else if (depth == 2) LAUNCH(2, 512);
+        else LAUNCH(3, 512);
+    } else {
+        if (depth <= 1) LAUNCH(1, 256);
+        else if (depth == 2) LAUNCH(2, 256);
+        else LAUNCH(3, 256);
+    }
 #undef LAUNCH
 }
 
