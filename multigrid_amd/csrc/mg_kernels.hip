@@ -70,47 +70,65 @@ __global__ __launch_bounds__(256) void k_smooth_colour(View u, View rhs, int64_t
     p[0] = u0 + omega * (g - u0);
 }
 
-// All sweeps of a small level inside one workgroup: u and rhs live in LDS, the
-// two colours are separated by workgroup barriers instead of kernel boundaries.
-// Used for the coarsest grid, whose 50 sweeps would otherwise be 100 launches
-// of a few thousand points each.
+// All sweeps of a small level inside one workgroup: u lives in LDS, the two colours are
+// separated by workgroup barriers instead of kernel boundaries.  Used for the coarsest grid,
+// whose 50 sweeps would otherwise be 100 launches of a few thousand points each.
+// Every thread keeps its points (at most P per colour) in registers for the whole launch:
+// LDS offset, right-hand side (constant over the sweeps) and current value, so a half-sweep is
+// six LDS reads, the update and one LDS write per point.
+template <int P>
 __global__ __launch_bounds__(1024) void k_smooth_lds(View u, View rhs, int nI, int nJ, int nK,
                                                      Coef c, double omega, int sweeps)
 {
-    extern __shared__ __align__(16) double sm[];
+    extern __shared__ __align__(16) double su[];  // dense copy of u, strides (uJ*uK, uK, 1)
     const int uI = (int)u.d[0], uJ = (int)u.d[1], uK = (int)u.d[2];
-    const int rJ = (int)rhs.d[1], rK = (int)rhs.d[2];
-    double *su = sm;                 // dense copy of u, strides (uJ*uK, uK, 1)
-    double *sr = sm + uI * uJ * uK;  // dense copy of rhs over 0..nI-1 planes
     const int tid = threadIdx.x;
     for (int p = tid; p < uI * uJ * uK; p += 1024) {
         const int k = p % uK, j = (p / uK) % uJ, i = p / (uK * uJ);
         su[p] = u.p[u.at(i, j, k)];
     }
-    for (int p = tid; p < nI * rJ * rK; p += 1024) {
-        const int k = p % rK, j = (p / rK) % rJ, i = p / (rK * rJ);
-        sr[p] = rhs.p[rhs.at(i, j, k)];
-    }
-    __syncthreads();
     const int half = (nK - 1) / 2;  // colour positions per row, at most
     const int rows = (nI - 2) * (nJ - 2);
     const int si = uJ * uK, sj = uK;
-    for (int s = 0; s < sweeps; s++)
-        for (int colour = 0; colour < 2; colour++) {
-            for (int idx = tid; idx < rows * half; idx += 1024) {
+    int off[2][P];      // LDS offset of the point, -1 = none
+    double b[2][P];     // its right-hand side
+#pragma unroll
+    for (int colour = 0; colour < 2; colour++)
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            const int idx = tid + q * 1024;
+            off[colour][q] = -1;
+            b[colour][q] = 0.0;
+            if (idx < rows * half) {
                 const int m = idx % half, t = idx / half;
                 const int j = 1 + t % (nJ - 2), i = 1 + t / (nJ - 2);
                 const int k = 1 + ((i + j + 1 + colour) & 1) + 2 * m;
                 if (k <= nK - 2) {
-                    double *p = su + i * si + j * sj + k;
-                    const double g = div_d(sr[(i * rJ + j) * rK + k] + c.cx * (p[-si] + p[si]) +
-                                           c.cy * (p[-sj] + p[sj]) + c.cz * (p[-1] + p[1]), c);
-                    const double u0 = p[0];
-                    p[0] = u0 + omega * (g - u0);
+                    off[colour][q] = i * si + j * sj + k;
+                    b[colour][q] = rhs.p[rhs.at(i, j, k)];
                 }
             }
+        }
+    __syncthreads();
+    for (int s = 0; s < sweeps; s++) {
+#pragma unroll
+        for (int colour = 0; colour < 2; colour++) {
+            double nu[P];
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+                const int o = off[colour][q] < 0 ? si + sj + 1 : off[colour][q];  // any interior point
+                const double *p = su + o;
+                const double g = div_d(b[colour][q] + c.cx * (p[-si] + p[si]) + c.cy * (p[-sj] + p[sj]) +
+                                       c.cz * (p[-1] + p[1]), c);
+                const double u0 = p[0];
+                nu[q] = u0 + omega * (g - u0);
+            }
+#pragma unroll
+            for (int q = 0; q < P; q++)
+                if (off[colour][q] >= 0) su[off[colour][q]] = nu[q];
             __syncthreads();
         }
+    }
     for (int p = tid; p < uI * uJ * uK; p += 1024) {
         const int k = p % uK, j = (p / uK) % uJ, i = p / (uK * uJ);
         u.p[u.at(i, j, k)] = su[p];
@@ -348,17 +366,25 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
 {
     if (n[0] < 3 || n[1] < 3 || n[2] < 3) return 0;
     const bool whole = u->i0 == 0 && r.lo == 0 && r.hi == u->d[0] && rhs.i0 == 0;
-    // small enough for one workgroup's LDS: all sweeps in a single launch
-    const size_t lds_bytes = sizeof(double) * (size_t)(u->d[0] * u->d[1] * u->d[2] + n[0] * rhs.d[1] * rhs.d[2]);
+    // small enough for one workgroup: all sweeps in a single launch, u in LDS, <= 4 points per
+    // colour per thread in registers
+    const size_t lds_bytes = sizeof(double) * (size_t)(u->d[0] * u->d[1] * u->d[2]);
+    const int64_t per_colour = (n[0] - 2) * (n[1] - 2) * ((n[2] - 1) / 2);
     static const bool lds_ok = [] {
         const char *e = getenv("MG_SMOOTH_LDS");
         if (e && !strcmp(e, "0")) return false;
-        return hipFuncSetAttribute((const void *)k_smooth_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+        return hipFuncSetAttribute((const void *)k_smooth_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kLdsSmoothMaxBytes) == hipSuccess &&
+               hipFuncSetAttribute((const void *)k_smooth_lds<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    kLdsSmoothMaxBytes) == hipSuccess;
     }();
-    if (whole && lds_ok && lds_bytes <= (size_t)kLdsSmoothMaxBytes && sweeps > 0) {
-        hipLaunchKernelGGL(k_smooth_lds, dim3(1), dim3(1024), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
-                           (int)n[2], c, omega, sweeps);
+    if (whole && lds_ok && lds_bytes <= (size_t)kLdsSmoothMaxBytes && per_colour <= 4 * 1024 && sweeps > 0) {
+        if (per_colour <= 2 * 1024)
+            hipLaunchKernelGGL(k_smooth_lds<2>, dim3(1), dim3(1024), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
+                               (int)n[2], c, omega, sweeps);
+        else
+            hipLaunchKernelGGL(k_smooth_lds<4>, dim3(1), dim3(1024), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
+                               (int)n[2], c, omega, sweeps);
         return 1;
     }
     const bool fused = alt && alt->p && use_fused_sweep(*u);

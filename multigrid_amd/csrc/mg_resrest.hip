@@ -34,20 +34,20 @@ __device__ __forceinline__ double wave_sum64(double v)
 
 // WJ x 2*WKP window of fine points; residual valid on the window minus one ring;
 // owned (norm, restriction centres) = window minus two rings.
-template <int WJ, int WKP, int D, bool STORE_RF>
-__global__ __launch_bounds__(256) void k_residual_restrict(View phi, View b, View Rf, View Rc, int nI,
+template <int WJ, int WKP, int D, bool STORE_RF, int NT>
+__global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View Rf, View Rc, int nI,
                                                            Coef c, double *__restrict__ partials,
                                                            int CI, int nchunks, int tiles_k, int rlo,
                                                            int rhi)
 {
     static_assert(WKP == 32, "row shuffles assume 32 lanes per row");
     constexpr int WK = 2 * WKP;
-    constexpr int G = 256 / WKP;   // row blocks per workgroup
+    constexpr int G = NT / WKP;    // row blocks per workgroup
     constexpr int Q = WJ / G;      // adjacent rows per lane
     constexpr int TJ = WJ - 4, TK = WK - 4;   // owned fine rows / columns (even)
     constexpr int TJC = TJ / 2, TKC = TK / 2; // coarse outputs per tile and coarse plane
     __shared__ double ring[3][WJ][WK];
-    __shared__ double red[4];
+    __shared__ double red[NT / 64];
 
     const int tid = threadIdx.x;
     const int m = tid % WKP, g = tid / WKP;
@@ -72,30 +72,31 @@ __global__ __launch_bounds__(256) void k_residual_restrict(View phi, View b, Vie
             return *reinterpret_cast<const d2 *>(v.p + v.at(ic, j, kkc));
         };
 
-        // planes p-1 (own rows only), p, p+1 and D planes in flight; index rq+1
-        d2 um1[Q], u0[Q + 2], up1[Q + 2], uf[D][Q + 2], b0[Q], bp1[Q], bf[D][Q];
-#pragma unroll
-        for (int q = 0; q < Q + 2; q++) {
-            u0[q] = load(phi, ia - 1, q - 1);
-            up1[q] = load(phi, ia, q - 1);
-#pragma unroll
-            for (int d = 0; d + 1 < D; d++) uf[d][q] = load(phi, ia + 1 + d, q - 1);
-        }
+        // Own rows: planes p-1, p, p+1 and D planes in flight.  The rows above and below the
+        // block (hN, hS) and the right-hand side are needed at plane p only and are cache hits or
+        // streamed once, so they are requested just one plane ahead: fewer live registers.
+        d2 um1[Q], u0[Q], up1[Q], uf[D][Q], hN0, hS0, hNn, hSn, b0[Q], bn[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             um1[q] = load(phi, ia - 2, q);
-            b0[q] = load(b, ia - 1, q);
-            bp1[q] = load(b, ia, q);
+            u0[q] = load(phi, ia - 1, q);
+            up1[q] = load(phi, ia, q);
 #pragma unroll
-            for (int d = 0; d + 1 < D; d++) bf[d][q] = load(b, ia + 1 + d, q);
+            for (int d = 0; d + 1 < D; d++) uf[d][q] = load(phi, ia + 1 + d, q);
+            b0[q] = load(b, ia - 1, q);
         }
+        hN0 = load(phi, ia - 1, -1);
+        hS0 = load(phi, ia - 1, Q);
 
         for (int p = ia - 1; p < ib; p++) {
             const int pl = min(p + 1 + D, ib);
 #pragma unroll
-            for (int q = 0; q < Q + 2; q++) uf[D - 1][q] = load(phi, pl, q - 1);
-#pragma unroll
-            for (int q = 0; q < Q; q++) bf[D - 1][q] = load(b, pl, q);
+            for (int q = 0; q < Q; q++) {
+                uf[D - 1][q] = load(phi, pl, q);
+                bn[q] = load(b, p + 1, q);
+            }
+            hNn = load(phi, p + 1, -1);
+            hSn = load(phi, p + 1, Q);
 
             if (p >= 0) {
                 double(*S)[WK] = ring[p % 3];
@@ -105,14 +106,16 @@ __global__ __launch_bounds__(256) void k_residual_restrict(View phi, View b, Vie
                 for (int q = 0; q < Q; q++) {
                     const int r = row_of(q);
                     const int j = j0 + r;
-                    const d2 u = u0[q + 1];
+                    const d2 u = u0[q];
+                    const d2 un = q == 0 ? hN0 : u0[q > 0 ? q - 1 : 0];
+                    const d2 us = q == Q - 1 ? hS0 : u0[q < Q - 1 ? q + 1 : Q - 1];
                     const double left = __shfl_up(u.y, 1, WKP);
                     const double right = __shfl_down(u.x, 1, WKP);
                     d2 rr;
-                    rr.x = u.x * c.d - b0[q].x - c.cx * (um1[q].x + up1[q + 1].x) -
-                           c.cy * (u0[q].x + u0[q + 2].x) - c.cz * (left + u.y);
-                    rr.y = u.y * c.d - b0[q].y - c.cx * (um1[q].y + up1[q + 1].y) -
-                           c.cy * (u0[q].y + u0[q + 2].y) - c.cz * (u.x + right);
+                    rr.x = u.x * c.d - b0[q].x - c.cx * (um1[q].x + up1[q].x) - c.cy * (un.x + us.x) -
+                           c.cz * (left + u.y);
+                    rr.y = u.y * c.d - b0[q].y - c.cx * (um1[q].y + up1[q].y) - c.cy * (un.y + us.y) -
+                           c.cz * (u.x + right);
                     const bool jface = j == 0 || j == nJ - 1;
                     if (iface || jface || kk == 0 || kk == nK - 1) rr.x = u.x - 0;
                     if (iface || jface || kk + 1 == 0 || kk + 1 == nK - 1) rr.y = u.y - 0;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void k_residual_restrict(View phi, View b, Vie
                     double(*A)[WK] = ring[(p - 2 + 3) % 3];  // plane 2I-1
                     double(*B)[WK] = ring[(p - 1) % 3];      // plane 2I
                     double(*C)[WK] = ring[p % 3];            // plane 2I+1
-                    for (int t = tid; t < TJC * TKC; t += 256) {
+                    for (int t = tid; t < TJC * TKC; t += NT) {
                         const int Jl = t / TKC, Kl = t % TKC;
                         const int J = tj * TJC + Jl, K = tk * TKC + Kl;
                         if (J < cJ && K < cK) {
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void k_residual_restrict(View phi, View b, Vie
                                     2 * F(-1, 0, 1) + 4 * F(0, 0, 1) + 2 * F(1, 0, 1) +
                                     F(-1, 1, 1) + 2 * F(0, 1, 1) + F(1, 1, 1);
 #undef F
-                                v = v / 64.0;
+                                v = v * 0.015625;  // == v / 64.0 exactly (power of two)
                             }
                             Rc.p[Rc.at(I, J, K)] = v;
                         }
@@ -166,26 +169,27 @@ __global__ __launch_bounds__(256) void k_residual_restrict(View phi, View b, Vie
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                um1[q] = u0[q + 1];
-                b0[q] = bp1[q];
-                bp1[q] = bf[0][q];
-#pragma unroll
-                for (int d = 0; d + 1 < D; d++) bf[d][q] = bf[d + 1][q];
-            }
-#pragma unroll
-            for (int q = 0; q < Q + 2; q++) {
+                um1[q] = u0[q];
                 u0[q] = up1[q];
                 up1[q] = uf[0][q];
 #pragma unroll
                 for (int d = 0; d + 1 < D; d++) uf[d][q] = uf[d + 1][q];
+                b0[q] = bn[q];
             }
+            hN0 = hNn;
+            hS0 = hSn;
         }
     }
     // workgroup partial sum, fixed order
     acc = wave_sum64(acc);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0) partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (tid == 0) {
+        double t = red[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; w++) t += red[w];
+        partials[blockIdx.x] = t;
+    }
 }
 
 struct Geometry {
@@ -200,9 +204,7 @@ Geometry geometry(const int64_t n[3], IRange r)
     const int64_t planes = r.hi - r.lo;
     g.tiles_j = (int)((n[1] + TJ - 1) / TJ);
     g.tiles_k = (int)((n[2] + TK - 1) / TK);
-    int nchunks = 8;
-    while ((int64_t)nchunks * g.tiles_j * g.tiles_k < 1024 && planes / (nchunks * 2) >= 8) nchunks *= 2;
-    if (planes < 16) nchunks = 1;
+    int nchunks = pick_chunks((int64_t)g.tiles_j * g.tiles_k, planes, 3, 2);
     static const int want = [] { const char *e = getenv("MG_RR_CHUNKS"); return e ? atoi(e) : 0; }();
     if (want > 0) nchunks = want;
     int CI = (int)((planes + nchunks - 1) / nchunks);
@@ -224,12 +226,21 @@ void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const 
                        double *partials, IRange r)
 {
     const Geometry g = geometry(n, r);
-    if (Rf.p)
-        hipLaunchKernelGGL((k_residual_restrict<32, 32, 2, true>), dim3(g.grid), dim3(256), 0, s, phi, b,
-                           Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi);
-    else
-        hipLaunchKernelGGL((k_residual_restrict<32, 32, 2, false>), dim3(g.grid), dim3(256), 0, s, phi, b,
-                           Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi);
+    static const int threads = [] { const char *e = getenv("MG_RR_NT"); return e ? atoi(e) : 256; }();
+    static const int depth = [] { const char *e = getenv("MG_RR_D"); return e ? atoi(e) : 2; }();
+#define LAUNCH(D, RF, NT)                                                                             \
+    hipLaunchKernelGGL((k_residual_restrict<32, 32, D, RF, NT>), dim3(g.grid), dim3(NT), 0, s, phi, b, \
+                       Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi)
+    if (Rf.p) {
+        LAUNCH(2, true, 256);
+    } else if (threads == 512) {
+        if (depth == 1) LAUNCH(1, false, 512);
+        else LAUNCH(2, false, 512);
+    } else {
+        if (depth == 1) LAUNCH(1, false, 256);
+        else LAUNCH(2, false, 256);
+    }
+#undef LAUNCH
 }
 
 }  // namespace mgk

@@ -230,10 +230,7 @@ void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t 
         if (nchunks < 1) nchunks = 1;
         while (nchunks > 1 && planes / nchunks < 8) nchunks--;
     } else {
-        // i-chunks: a multiple of 8 (one group per XCD) and enough workgroups to fill 256 CUs
-        nchunks = 8;
-        while ((int64_t)nchunks * tiles < 1024 && planes / (nchunks * 2) >= 8) nchunks *= 2;
-        if (planes < 16) nchunks = 1;
+        nchunks = pick_chunks(tiles, planes, 4);
     }
     if (want_chunks > 0) nchunks = want_chunks;
     const int CI = (int)((planes + nchunks - 1) / nchunks);
