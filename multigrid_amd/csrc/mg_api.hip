@@ -103,6 +103,7 @@ struct mg_handle {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bool have_rho = false, have_phi = false;
     bool fused_residual = true;  // R_0 never stored (default); false with MG_FLAG_KEEP_FINE_RESIDUAL
+    bool correction_pending = false;  // phi -= P(eps_1) of the last iteration not applied yet
     double last_ms = 0;
     // profiling
     bool profiling = false;
@@ -165,16 +166,33 @@ void drain_profile(mg_handle *h)
     h->recs.clear();
 }
 
-// Steps 1)-2b) of the reference iteration: smooth the fine grid, residual, norm.
+// Step 6) as its own launch: phi -= P(eps_1).
+void flush_correction(mg_handle *h)
+{
+    if (!h->correction_pending) return;
+    Prof p(h, MG_T_PROLONG_CORRECT, 17.0 * (double)count3(h->lv[0].n));
+    mgk::prolong_correct(h->stream, h->lv[1].eps, h->phi, h->lv[0].n, IRange{0, h->lv[0].n[0]});
+    h->correction_pending = false;
+}
+
+// Step 6) of the previous iteration, if still pending, and steps 1)-2b) of this one: correct,
+// smooth the fine grid, residual, norm.  The correction phi -= P(eps_1) is folded into the first
+// fine sweep where the single-pass sweep kernel runs (one pass over phi less per iteration).
 // Leaves sum(R_h^2) in h->d_sum and queues its copy to h->h_sum.
 void enqueue_smooth_residual(mg_handle *h)
 {
     Level &f = h->lv[0];
     const double N = (double)count3(f.n);
-    {
+    const IRange all{0, f.n[0]};
+    if (h->correction_pending && f.nu > 0) {
+        Prof p(h, MG_T_SMOOTH_FINE, (32.0 * f.nu + 17.0) * N);
+        p.launches = mgk::prolong_smooth_rb(h->stream, h->lv[1].eps, true, &h->phi, &h->phi_alt, h->b, f.n, f.c,
+                                            h->cfg.omega, f.nu, all);
+        h->correction_pending = false;
+    } else {
+        flush_correction(h);
         Prof p(h, MG_T_SMOOTH_FINE, 32.0 * N * f.nu);
-        p.launches = mgk::smooth_rb(h->stream, &h->phi, &h->phi_alt, h->b, f.n, f.c, h->cfg.omega, f.nu,
-                                    IRange{0, f.n[0]});
+        p.launches = mgk::smooth_rb(h->stream, &h->phi, &h->phi_alt, h->b, f.n, f.c, h->cfg.omega, f.nu, all);
     }
     int64_t np;
     if (h->fused_residual) {
@@ -182,13 +200,12 @@ void enqueue_smooth_residual(mg_handle *h)
         Prof p(h, MG_T_RESIDUAL, 17.0 * N);
         View none = f.R;
         none.p = nullptr;
-        mgk::residual_restrict(h->stream, h->phi, h->b, none, h->lv[1].R, f.n, f.c, h->partials,
-                               IRange{0, f.n[0]});
-        np = mgk::residual_restrict_partials(f.n, IRange{0, f.n[0]});
+        mgk::residual_restrict(h->stream, h->phi, h->b, none, h->lv[1].R, f.n, f.c, h->partials, all);
+        np = mgk::residual_restrict_partials(f.n, all);
     } else {
         Prof p(h, MG_T_RESIDUAL, 24.0 * N);
-        mgk::residual(h->stream, h->phi, h->b, f.R, f.n, f.c, h->partials, IRange{0, f.n[0]});
-        np = mgk::residual_partials(f.n, IRange{0, f.n[0]});
+        mgk::residual(h->stream, h->phi, h->b, f.R, f.n, f.c, h->partials, all);
+        np = mgk::residual_partials(f.n, all);
     }
     {
         Prof p(h, MG_T_NORM, 8.0 * (double)np);
@@ -197,7 +214,8 @@ void enqueue_smooth_residual(mg_handle *h)
     hipMemcpyAsync(h->h_sum, h->d_sum, sizeof(double), hipMemcpyDeviceToHost, h->stream);
 }
 
-// Steps 3)-6): restrict down, (smooth, prolong) up, correct.
+// Steps 3)-5): restrict down, (prolong, smooth) up.  Step 6), phi -= P(eps_1), is left pending:
+// the next iteration's first sweep applies it, or flush_correction() when no iteration follows.
 void enqueue_coarse_correction(mg_handle *h)
 {
     const int L = h->L;
@@ -207,20 +225,19 @@ void enqueue_coarse_correction(mg_handle *h)
     }
     for (int l = L; l >= 1; l--) {
         Level &v = h->lv[l];
+        const IRange all{0, v.eps.d[0]};
+        const double Nl = (double)count3(v.n);
         if (l < L) {
-            Prof p(h, MG_T_PROLONG, 9.0 * (double)count3(v.n));
-            mgk::prolong(h->stream, h->lv[l + 1].eps, v.eps, v.n, IRange{0, v.n[0]});
-        }
-        {
-            Prof p(h, MG_T_SMOOTH_COARSE, 32.0 * (double)count3(v.n) * v.nu);
-            p.launches = mgk::smooth_rb(h->stream, &v.eps, &v.eps_alt, v.R, v.n, v.c, h->cfg.omega, v.nu,
-                                        IRange{0, v.eps.d[0]});
+            // prolongation of eps_{l+1} as the initial guess, then nu_l sweeps
+            Prof p(h, MG_T_SMOOTH_COARSE, (32.0 * v.nu + 9.0) * Nl);
+            p.launches = mgk::prolong_smooth_rb(h->stream, h->lv[l + 1].eps, false, &v.eps, &v.eps_alt, v.R, v.n,
+                                                v.c, h->cfg.omega, v.nu, all);
+        } else {
+            Prof p(h, MG_T_SMOOTH_COARSE, 32.0 * Nl * v.nu);
+            p.launches = mgk::smooth_rb(h->stream, &v.eps, &v.eps_alt, v.R, v.n, v.c, h->cfg.omega, v.nu, all);
         }
     }
-    {
-        Prof p(h, MG_T_PROLONG_CORRECT, 17.0 * (double)count3(h->lv[0].n));
-        mgk::prolong_correct(h->stream, h->lv[1].eps, h->phi, h->lv[0].n, IRange{0, h->lv[0].n[0]});
-    }
+    h->correction_pending = true;
 }
 
 double l2_from_sum(const mg_handle *h, double sum)
@@ -450,6 +467,7 @@ int mg_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsigned
         enqueue_coarse_correction(h);
         HIP_TRY(hipGetLastError());
     }
+    flush_correction(h);  // max_it exhausted: the last iteration's correction still counts
     HIP_TRY(hipEventRecord(h->ev_b, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     float ms = 0;
@@ -470,6 +488,7 @@ int mg_vcycles(mg_handle *h, unsigned count, double *L2)
         enqueue_smooth_residual(h);
         enqueue_coarse_correction(h);
     }
+    flush_correction(h);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_b, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -92,6 +92,15 @@ void smooth_colour(hipStream_t s, View u, View rhs, const int64_t n[3], Coef c, 
 // [r.lo-2, r.hi+2) as far as they exist in the global array (gI planes).
 void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c,
                     double omega, IRange r);
+// The same with the operation that precedes the sweep applied to u_in as it is loaded:
+// correct: u_in := u_in - P(ec) (fine grid, phi -= eps_h); otherwise u_in := P(ec) over
+// 0..n-2 (a coarse level's prolongated initial guess).  ec = eps of the next coarser level.
+void sweep_rb_fused_onload(hipStream_t s, View uin, View uout, View rhs, View ec, bool correct,
+                           const int64_t n[3], Coef c, double omega, IRange r);
+// `sweeps` red-black sweeps preceded by the prolongation from ec (correct: by phi -= P(ec)):
+// fused into the first sweep where the single-pass kernel is used, separate launches otherwise.
+int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, View rhs,
+                      const int64_t n[3], Coef c, double omega, int sweeps, IRange r);
 // `sweeps` red-black sweeps on planes r of *u.  May ping-pong between *u and *alt (same
 // shape); on return *u is the view holding the result.  Returns the kernels launched.
 int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c, double omega,

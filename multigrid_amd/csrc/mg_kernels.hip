@@ -410,6 +410,24 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
     return fused ? sweeps : 2 * sweeps;
 }
 
+int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, View rhs,
+                      const int64_t n[3], Coef c, double omega, int sweeps, IRange r)
+{
+    static const bool allow = getenv("MG_NO_ONLOAD") == nullptr;  // A/B: force separate launches
+    const bool whole = u->i0 == 0 && r.lo == 0 && r.hi == u->d[0];
+    if (allow && whole && sweeps > 0 && alt && alt->p && use_fused_sweep(*u)) {
+        sweep_rb_fused_onload(s, *u, *alt, rhs, ec, correct, n, c, omega, r);
+        View t = *u;
+        *u = *alt;
+        *alt = t;
+        return 1 + smooth_rb(s, u, alt, rhs, n, c, omega, sweeps - 1, r);
+    }
+    IRange pr{r.lo, r.hi > n[0] ? n[0] : r.hi};
+    if (correct) prolong_correct(s, ec, *u, n, pr);
+    else prolong(s, ec, *u, n, pr);
+    return 1 + smooth_rb(s, u, alt, rhs, n, c, omega, sweeps, r);
+}
+
 void residual(hipStream_t s, View phi, View b, View R, const int64_t n[3], Coef c, double *partials,
               IRange r)
 {

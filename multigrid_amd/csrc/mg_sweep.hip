@@ -39,39 +39,45 @@ __device__ __forceinline__ d2 put(d2 v, int e, double x)
     return r;
 }
 
+// What to do with u_in as it is loaded, before the sweep sees it.  The prolongation that
+// precedes the first sweep of a level (and the correction phi -= P(eps) that precedes the first
+// fine sweep of the next iteration) only needs the coarse array, so applying it on the fly saves
+// writing the prolongated field and reading it back (16 bytes per point).
+enum : int {
+    kLoadPlain = 0,
+    kLoadCorrect = 1,  // u := u - P(ec) on 1..n-2          (reference cpp/PotentialSolver.cpp:4170-4214)
+    kLoadProlong = 2   // u := P(ec) on 0..n-2, 0 at index 0 (reference cpp/PotentialSolver.cpp:3940-3976)
+};
+
 // WJ rows x 2*WKP columns per window; outputs are the window minus two rings.
 // D = planes of u (and of the right-hand side) requested ahead of use: the march is
 // latency bound unless several planes per workgroup are in flight.
-template <int WJ, int WKP, int D, int NT>
-__global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, int nI, int nJ,
+template <int WJ, int WKP, int D, int NT, int MODE>
+__global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, View ec, int nI, int nJ,
                                                   int nK, Coef c, double omega, int CI, int nchunks,
-                                                  int tiles_k, int rlo, int rhi, int xcd_map)
+                                                  int tiles_k, int rlo, int rhi)
 {
     constexpr int WK = 2 * WKP;
     constexpr int TJ = WJ - 4, TK = WK - 4;
     constexpr int RPP = NT / WKP;   // rows covered by one pass of the workgroup
     constexpr int Q = WJ / RPP;     // pair-columns owned by a thread
+    constexpr int CJ = WJ / 2 + 1, CK = WKP + 1;  // coarse footprint of the window
+    constexpr int CKP = CK + 1;                   // padded row
+    constexpr int CE = (CJ * CK + NT - 1) / NT;   // coarse elements staged per thread
     static_assert(WJ % RPP == 0, "window rows must be a multiple of rows per pass");
     __shared__ double lds[3][WJ][WK];
+    __shared__ double cl[2][CJ][CKP];  // staged coarse planes; unused (and not allocated) in plain mode
 
     const int tid = threadIdx.x;
     const int m = tid % WKP, rr = tid / WKP;
-    // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 labels the XCD).  Remap so that
-    // each XCD works on a contiguous run of (chunk, tile) items: windows that share halo columns and
-    // rows then run on one XCD at about the same time, and the second fetch of a halo line hits
-    // that XCD's L2.  Speed only: any mapping gives the same result.
-    int chunk, tile;
-    if (xcd_map) {
-        const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7;
-        const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int w = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + idx;
-        const int ntiles = nwg / nchunks;
-        chunk = w / ntiles;
-        tile = w % ntiles;
-    } else {
-        chunk = blockIdx.x % nchunks;
-        tile = blockIdx.x / nchunks;
-    }
+    // Row of this lane within a pass of RPP rows.  The two 32-lane halves of a wave take rows
+    // RPP/2 apart instead of adjacent ones: rows of equal parity have their red point in the same
+    // pair element and the same prolongation case, so the wave does not diverge.
+    const int rw = (rr >> 1) + (RPP / 2) * (rr & 1);
+    // chunk index fastest: with a multiple of 8 chunks all windows of a chunk share blockIdx % 8,
+    // i.e. one XCD and its L2
+    const int chunk = blockIdx.x % nchunks;
+    const int tile = blockIdx.x / nchunks;
     const int tk = tile % tiles_k, tj = tile / tiles_k;
     const int j0 = tj * TJ - 2, k0 = tk * TK - 2;
     const int uJ = (int)uin.d[1], uK = (int)uin.d[2];
@@ -90,14 +96,73 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
     const int kku = min(max(kk, 0), (uK - 1) & ~1);
     const int kkr = min(max(kk, 0), (rK - 1) & ~1);
     auto load_u = [&](int i, int q) -> d2 {
-        const int j = min(max(j0 + q * RPP + rr, 0), uJ - 1);
+        const int j = min(max(j0 + q * RPP + rw, 0), uJ - 1);
         const int ic = min(max(i, ulo), uhi);
         return *reinterpret_cast<const d2 *>(uin.p + uin.at(ic, j, kku));
     };
     auto load_b = [&](int i, int q) -> d2 {
-        const int j = min(max(j0 + q * RPP + rr, 0), rJ - 1);
+        const int j = min(max(j0 + q * RPP + rw, 0), rJ - 1);
         const int ic = min(max(i, blo), bhi);
         return *reinterpret_cast<const d2 *>(rhs.p + rhs.at(ic, j, kkr));
+    };
+
+    // ---- coarse tile staging (MODE != plain): coarse planes I and I+1 live in cl[I&1], cl[(I+1)&1]
+    const int J0 = j0 >> 1, K0 = k0 >> 1;  // j0, k0 are even (arithmetic shift keeps -2 -> -1)
+    auto coarse_elem = [&](int I, int e) -> double {
+        const int Jl = e / CK, Kl = e % CK;
+        const int Ic = min(max(I, (int)ec.i0), (int)ec.i_end() - 1);
+        const int Jc = min(max(J0 + Jl, 0), (int)ec.d[1] - 1);
+        const int Kc = min(max(K0 + Kl, 0), (int)ec.d[2] - 1);
+        return ec.p[ec.at(Ic, Jc, Kc)];
+    };
+    auto stage_write = [&](int I, const double (&v)[CE]) {
+#pragma unroll
+        for (int t = 0; t < CE; t++) {
+            const int e = tid + t * NT;
+            if (e < CJ * CK) cl[I & 1][e / CK][e % CK] = v[t];
+        }
+    };
+    // u as the sweep must see it: the loaded pair of (plane f, window row r) after the on-load
+    // operation.  Reads the staged coarse planes f>>1 and (f>>1)+1.
+    auto fix = [&](d2 raw, int f, int r) -> d2 {
+        if constexpr (MODE == kLoadPlain) return raw;
+        const int j = j0 + r;
+        const int I = f >> 1, Jl = r >> 1, Kl = m;
+        const bool oi = f & 1, oj = j & 1;
+        const double(*A)[CKP] = cl[I & 1];
+        const double(*B)[CKP] = cl[(I + 1) & 1];
+        // the eight corner values; the sums below follow the reference's association order
+        const double c000 = A[Jl][Kl], c010 = A[Jl + 1][Kl], c001 = A[Jl][Kl + 1], c011 = A[Jl + 1][Kl + 1];
+        const double c100 = B[Jl][Kl], c110 = B[Jl + 1][Kl], c101 = B[Jl][Kl + 1], c111 = B[Jl + 1][Kl + 1];
+        double vx, vy;  // interpolant at k = kk (even) and kk+1 (odd)
+        if (!oi && !oj) {
+            vx = c000;
+            vy = 0.5 * (c000 + c001);
+        } else if (oi && !oj) {
+            const double s = c000 + c100;
+            vx = 0.5 * s;
+            vy = 0.25 * ((s + c001) + c101);
+        } else if (!oi && oj) {
+            const double s = c000 + c010;
+            vx = 0.5 * s;
+            vy = 0.25 * ((s + c001) + c011);
+        } else {
+            const double s = ((c000 + c100) + c010) + c110;
+            vx = 0.25 * s;
+            vy = 0.125 * ((((s + c001) + c101) + c011) + c111);
+        }
+        d2 out = raw;
+        const bool fj = f <= nI - 2 && j <= nJ - 2;  // inside the prolongation's loop range
+        if (MODE == kLoadCorrect) {
+            const bool in = fj && f >= 1 && j >= 1;
+            if (in && kk >= 1 && kk <= nK - 2) out.x = raw.x - vx;
+            if (in && kk + 1 <= nK - 2) out.y = raw.y - vy;
+        } else {
+            const bool zero = f == 0 || j == 0;
+            if (fj && kk <= nK - 2) out.x = (zero || kk == 0) ? 0.0 : vx;
+            if (fj && kk + 1 <= nK - 2) out.y = zero ? 0.0 : vy;
+        }
+        return out;
     };
 
     // u planes p-2, p-1, p, p+1 of the owned pair-columns, then the D planes in flight;
@@ -116,7 +181,34 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
             vf[d][q] = load_u(ia + 1 + d, q);
             bf[d][q] = load_b(ia + d, q);
         }
-        const int r = q * RPP + rr;
+    }
+    if (MODE != kLoadPlain) {
+        // the three planes loaded above are needed at once: fix them plane by plane, staging the
+        // coarse planes each one needs (a barrier per step; once per workgroup)
+        double cv[CE];
+        for (int step = 0; step < 3; step++) {
+            const int f = ia - 2 + step, I = f >> 1;
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < CE; t++) cv[t] = coarse_elem(I, tid + t * NT);
+            stage_write(I, cv);
+#pragma unroll
+            for (int t = 0; t < CE; t++) cv[t] = coarse_elem(I + 1, tid + t * NT);
+            stage_write(I + 1, cv);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int r = q * RPP + rw;
+                if (step == 0) vm1[q] = fix(vm1[q], f, r);
+                else if (step == 1) v0[q] = fix(v0[q], f, r);
+                else vp1[q] = fix(vp1[q], f, r);
+            }
+        }
+        // staged now: planes ia>>1 and (ia>>1)+1, which is also what plane ia+1 needs
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int r = q * RPP + rw;
         *reinterpret_cast<d2 *>(&lds[(ia - 1 + 3) % 3][r][2 * m]) = v0[q];
     }
 
@@ -126,13 +218,22 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
             vf[D - 1][q] = load_u(min(p + 1 + D, ib + 1), q);
             bf[D - 1][q] = load_b(min(p + D, ib), q);
         }
+        // plane f = p+2 is fixed at the end of this iteration.  When f is even it needs coarse
+        // plane f/2 only (already staged); plane f/2+1, needed from f+1 on, is fetched now and
+        // written to the slot plane f/2-1 occupied (last read for f-1, two barriers ago).
+        const int f = p + 2;
+        double cv[CE];
+        if (MODE != kLoadPlain && !(f & 1)) {
+#pragma unroll
+            for (int t = 0; t < CE; t++) cv[t] = coarse_elem((f >> 1) + 1, tid + t * NT);
+        }
         __syncthreads();
         // ---- red points of plane p (neighbours: old black values) ----------
         if (p >= 1 && p <= nI - 2) {
             double(*X)[WK] = lds[(p + 3) % 3];
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                const int r = q * RPP + rr;
+                const int r = q * RPP + rw;
                 const int j = j0 + r;
                 const int e = (p + j) & 1;
                 const int col = 2 * m + e;
@@ -149,6 +250,7 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
                 X[r][col] = un;
             }
         }
+        if (MODE != kLoadPlain && !(f & 1)) stage_write((f >> 1) + 1, cv);
         __syncthreads();
         // ---- black points of plane p-1 (neighbours: new red values), store --
         const int pb = p - 1;
@@ -157,7 +259,7 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
                 double(*Y)[WK] = lds[(pb + 3) % 3];
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    const int r = q * RPP + rr;
+                    const int r = q * RPP + rw;
                     const int j = j0 + r;
                     const int e = (p + j) & 1;  // black of plane p-1 sits where red of plane p does
                     const int col = 2 * m + e;
@@ -174,21 +276,21 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                const int r = q * RPP + rr;
+                const int r = q * RPP + rw;
                 const int j = j0 + r;
                 if (r >= 2 && r <= WJ - 3 && m >= 1 && m <= WKP - 2 && j < uJ && kk < uK)
                     *reinterpret_cast<d2 *>(uout.p + uout.at(pb, j, kk)) = vm1[q];
             }
         }
-        // plane p+1 (old values) into the LDS slot plane p-2 occupied
+        // plane p+1 into the LDS slot plane p-2 occupied; plane p+2 arrives and is fixed
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            const int r = q * RPP + rr;
+            const int r = q * RPP + rw;
             *reinterpret_cast<d2 *>(&lds[(p + 1 + 3) % 3][r][2 * m]) = vp1[q];
             vm2[q] = vm1[q];
             vm1[q] = v0[q];
             v0[q] = vp1[q];
-            vp1[q] = vf[0][q];
+            vp1[q] = fix(vf[0][q], f, r);
             bm1[q] = b0[q];
             b0[q] = bf[0][q];
 #pragma unroll
@@ -210,46 +312,42 @@ static int env_int(const char *name, int dflt)
 
 // One full red-black sweep u_in -> u_out: planes r of u_out, updated over 1..n-2 per axis
 // (n = level size); every other element of those planes is copied through unchanged.
-void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c,
-                    double omega, IRange r)
+// load_op (kLoad*) is applied to u_in on the fly with the coarse array ec.
+static void launch_sweep(hipStream_t s, View uin, View uout, View rhs, View ec, int load_op,
+                         const int64_t n[3], Coef c, double omega, IRange r)
 {
-    constexpr int WJ = 32, WKP = 32;
+    constexpr int WJ = 32, WKP = 32, D = 2, NT = 256;
     constexpr int TJ = WJ - 4, TK = 2 * WKP - 4;
-    static const int depth = env_int("MG_SWEEP_D", 2);         // tuning knobs (A/B runs)
-    static const int want_chunks = env_int("MG_SWEEP_CHUNKS", 0);
+    static const int want_chunks = env_int("MG_SWEEP_CHUNKS", 0);  // tuning knob (A/B runs)
     const int64_t planes = r.hi - r.lo;
     if (planes <= 0) return;
     const int tiles_j = (int)((uin.d[1] + TJ - 1) / TJ);
     const int tiles_k = (int)((uin.d[2] + TK - 1) / TK);
-    static const int xcd_map = env_int("MG_SWEEP_MAP", 0);
     const int tiles = tiles_j * tiles_k;
-    int nchunks;
-    if (xcd_map) {
-        // one cohort: about two workgroups per CU resident at once, all started together
-        nchunks = (int)((512 + tiles / 2) / tiles);
-        if (nchunks < 1) nchunks = 1;
-        while (nchunks > 1 && planes / nchunks < 8) nchunks--;
-    } else {
-        nchunks = pick_chunks(tiles, planes, 4);
-    }
+    int nchunks = pick_chunks(tiles, planes, 4);
     if (want_chunks > 0) nchunks = want_chunks;
     const int CI = (int)((planes + nchunks - 1) / nchunks);
     const unsigned grid = (unsigned)(nchunks * tiles);
-    static const int threads = env_int("MG_SWEEP_NT", 256);
-#define LAUNCH(D, NT)                                                                              \
-    hipLaunchKernelGGL((k_sweep_rb<WJ, WKP, D, NT>), dim3(grid), dim3(NT), 0, s, uin, uout, rhs,   \
-                       (int)n[0], (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k, (int)r.lo, \
-                       (int)r.hi, xcd_map)
-    if (threads == 512) {
-        if (depth <= 1) LAUNCH(1, 512);
-        else if (depth == 2) LAUNCH(2, 512);
-        else LAUNCH(3, 512);
-    } else {
-        if (depth <= 1) LAUNCH(1, 256);
-        else if (depth == 2) LAUNCH(2, 256);
-        else LAUNCH(3, 256);
-    }
+#define LAUNCH(MODE)                                                                                 \
+    hipLaunchKernelGGL((k_sweep_rb<WJ, WKP, D, NT, MODE>), dim3(grid), dim3(NT), 0, s, uin, uout, rhs, \
+                       ec, (int)n[0], (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k, (int)r.lo, \
+                       (int)r.hi)
+    if (load_op == kLoadCorrect) LAUNCH(kLoadCorrect);
+    else if (load_op == kLoadProlong) LAUNCH(kLoadProlong);
+    else LAUNCH(kLoadPlain);
 #undef LAUNCH
+}
+
+void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c,
+                    double omega, IRange r)
+{
+    launch_sweep(s, uin, uout, rhs, uin, kLoadPlain, n, c, omega, r);
+}
+
+void sweep_rb_fused_onload(hipStream_t s, View uin, View uout, View rhs, View ec, bool correct,
+                           const int64_t n[3], Coef c, double omega, IRange r)
+{
+    launch_sweep(s, uin, uout, rhs, ec, correct ? kLoadCorrect : kLoadProlong, n, c, omega, r);
 }
 
 }  // namespace mgk
