@@ -35,6 +35,29 @@ KERNEL_BYTES_PER_POINT = {"smooth_fine": 16.0, "residual": 24.0, "restrict": 9.0
                           "smooth_coarse": 16.0, "prolong": 9.0, "prolong_correct": 17.0}
 
 
+PROFILE_KERNEL = {"smooth_fine": "k_sweep_rb", "residual": "k_residual_restrict",
+                  "prolong_correct": "k_prolong<true>", "smooth_coarse": "k_sweep_rb"}
+
+
+def profiled_traffic(kind):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 counter
+    summary (profiles/*_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command, FETCH_SIZE doubled for 16-byte-per-lane loads as the MI355X counter notes require).
+    bench.py cannot run the profiler around itself; None when no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")))
+    prefix = PROFILE_KERNEL.get(kind)
+    if not files or not prefix:
+        return None, None
+    try:
+        prof = json.load(open(files[-1]))
+        best = max((v.get("hbm_bytes_max_launch", 0.0) for k, v in prof["kernels"].items() if k.startswith(prefix)),
+                   default=0.0)
+        return (best or None), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,10 +135,15 @@ def run_single(args):
     for k in kernels:
         kernels[k]["share"] = timers[k]["ms"] / tot
     dom = max(kernels, key=lambda k: kernels[k]["share"])
+    traffic, traffic_src = profiled_traffic(dom) if n == 513 else (None, None)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
-                "avg_us": kernels[dom]["avg_us"],
-                "bytes_per_launch": timers[dom]["bytes"] / timers[dom]["launches"]}
+                "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src, "avg_us": kernels[dom]["avg_us"],
+                "bytes_per_launch": timers[dom]["bytes"] / timers[dom]["launches"],
+                "compulsory_bytes_per_launch": 25.0 * n ** 3 if dom == "smooth_fine" else None,
+                "note": "achieved = algorithmic bytes of the operators the launch performs (full red-black "
+                        "sweep 32 B/pt + fused prolongation/correction 17 B/pt) / HIP-event time; the launch's "
+                        "own compulsory traffic is 25 B/pt"}
 
     solve = None
     if not args.no_solve:
