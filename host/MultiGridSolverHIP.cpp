@@ -57,7 +57,7 @@ bool MultiGridSolverHIP::solve()
     check(mg_set_rho(handle, pack(world.rho, stage)), "mg_set_rho");
     check(mg_set_phi(handle, pack(world.phi, stage)), "mg_set_phi");
     int converged = 0;
-    check(mg_solve(handle, max_solver_it, tolerance, &converged, &last_cycles, &last_l2), "mg_solve");
+    check(iterate(&converged), "solve");
     Field &phi = world.phi;
     if (rows_contiguous(phi)) {
         check(mg_get_phi(handle, phi[0][0]), "mg_get_phi");
@@ -68,8 +68,47 @@ bool MultiGridSolverHIP::solve()
             for (int j = 0; j < phi.nj; j++)
                 std::memcpy(phi[i][j], &stage[(std::size_t(i) * phi.nj + j) * phi.nk], sizeof(double) * phi.nk);
     }
+    solved = true;
     if (!converged) std::cerr << "GS failed to converge, L2=" << last_l2 << std::endl;
     return converged != 0;
+}
+
+int MultiGridSolverHIP::iterate(int *converged)
+{
+    return mg_solve(handle, max_solver_it, tolerance, converged, &last_cycles, &last_l2);
+}
+
+int GaussSeidelSolverHIP::iterate(int *converged)
+{
+    return mg_gs_solve(handle, max_solver_it, tolerance, converged, &last_cycles, &last_l2);
+}
+
+// E = -grad(phi) from the device-resident potential.  Before the first solve() the device holds
+// no potential yet: upload world.phi first.
+void MultiGridSolverHIP::computeEF()
+{
+    if (!solved) check(mg_set_phi(handle, pack(world.phi, stage)), "mg_set_phi");
+    check(mg_compute_ef(handle), "mg_compute_ef");
+    Field3 &ef = world.ef;
+    static_assert(sizeof(double3) == 3 * sizeof(double), "double3 must be three packed doubles");
+    const std::size_t row = std::size_t(ef.nk) * 3;
+    const double *base = reinterpret_cast<const double *>(ef[0][0]);
+    bool contiguous = true;
+    for (int i = 0; i < ef.ni && contiguous; i++)
+        for (int j = 0; j < ef.nj; j++)
+            if (reinterpret_cast<const double *>(ef[i][j]) != base + (std::size_t(i) * ef.nj + j) * row) {
+                contiguous = false;
+                break;
+            }
+    if (contiguous) {
+        check(mg_get_ef(handle, reinterpret_cast<double *>(ef[0][0])), "mg_get_ef");
+        return;
+    }
+    stage.resize(std::size_t(ef.ni) * ef.nj * row);
+    check(mg_get_ef(handle, stage.data()), "mg_get_ef");
+    for (int i = 0; i < ef.ni; i++)
+        for (int j = 0; j < ef.nj; j++)
+            std::memcpy(static_cast<void *>(ef[i][j]), &stage[(std::size_t(i) * ef.nj + j) * row], sizeof(double) * row);
 }
 
 double MultiGridSolverHIP::deviceMilliseconds() const

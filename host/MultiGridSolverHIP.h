@@ -1,9 +1,13 @@
 // HIP-backed multigrid solvers behind the reference's PotentialSolver interface.
 //
 //   MultiGridSolverHIP             depth-generic V-cycle solver on an MI355X through libmg_hip
-//   hip::MultiGridSolver, V2..V5   same constructor signature (World&, int max_it, double tol) as
-//                                  the reference classes of those names
-//                                  (cpp/PotentialSolver.h:171-272), with their sweep schedules
+//   GaussSeidelSolverHIP           the plain SOR loop of GaussSeidelSolver (cpp/PotentialSolver.cpp:235-291)
+//   hip::MultiGridSolver, V2..V5,  same constructor signature (World&, int max_it, double tol) as
+//   hip::GaussSeidelSolver         the reference classes of those names
+//                                  (cpp/PotentialSolver.h:70-87, :171-272), with their sweep schedules
+//
+// computeEF() of these classes differentiates the potential the solve left in device memory
+// (one kernel, no upload) and copies E into world.ef; results are bit-identical to the host loop.
 //
 // solve() contract (unchanged from the reference): reads world.phi (initial guess and
 // Dirichlet face values), world.rho, world.getDh(); overwrites world.phi; returns true iff
@@ -27,13 +31,15 @@ struct mg_handle;
 
 class MultiGridSolverHIP : public PotentialSolver {
 public:
-    // depth = number of coarse grids (1..5 = the reference's MultiGridSolver, V2, .. V5)
+    // depth = number of coarse grids (1..5 = the reference's MultiGridSolver, V2, .. V5;
+    // 0 only through GaussSeidelSolverHIP)
     MultiGridSolverHIP(World &world, int max_it, double tol, int depth, int device = 0);
     ~MultiGridSolverHIP() override;
     MultiGridSolverHIP(const MultiGridSolverHIP &) = delete;
     MultiGridSolverHIP &operator=(const MultiGridSolverHIP &) = delete;
 
     bool solve() override;
+    void computeEF() override;
 
     // diagnostics of the last solve()
     unsigned cycles() const { return last_cycles; }
@@ -41,15 +47,31 @@ public:
     double deviceMilliseconds() const;
 
 protected:
+    // iteration loop run on the device between the upload and the download of solve()
+    virtual int iterate(int *converged);
+
     unsigned max_solver_it;  // same names as the reference members (cpp/PotentialSolver.h:85-86)
     double tolerance;
     mg_handle *handle = nullptr;
     std::vector<double> stage;  // dense copy of a field whose rows are not contiguous
     unsigned last_cycles = 0;
     double last_l2 = 0;
+    bool solved = false;  // the device holds the potential of the last solve()
+};
+
+// Red-black SOR sweeps with the reference's stopping rule (norm of the interior residual tested
+// every 25th sweep); a handle without coarse grids.
+class GaussSeidelSolverHIP : public MultiGridSolverHIP {
+public:
+    GaussSeidelSolverHIP(World &world, int max_it, double tol, int device = 0)
+        : MultiGridSolverHIP(world, max_it, tol, 0, device) {}
+
+protected:
+    int iterate(int *converged) override;
 };
 
 namespace hip {
+struct GaussSeidelSolver : GaussSeidelSolverHIP { GaussSeidelSolver(World &w, int it, double tol) : GaussSeidelSolverHIP(w, it, tol) {} };
 struct MultiGridSolver : MultiGridSolverHIP { MultiGridSolver(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 1) {} };
 struct MultiGridSolverV2 : MultiGridSolverHIP { MultiGridSolverV2(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 2) {} };
 struct MultiGridSolverV3 : MultiGridSolverHIP { MultiGridSolverV3(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 3) {} };

@@ -11,8 +11,10 @@ public:
     virtual ~PotentialSolver() {}
     virtual bool solve() = 0;
     // E = -grad(phi), central differences inside, one-sided 3-point on the faces
-    // (cpp/PotentialSolver.cpp:418-458)
-    void computeEF();
+    // (cpp/PotentialSolver.cpp:418-458): host loop.  Virtual here (the reference's is not) so
+    // that the device solvers can answer the driver's solver->computeEF() call
+    // (cpp/Main.cpp:126,166) from the potential they still hold in device memory.
+    virtual void computeEF();
 
 protected:
     World &world;

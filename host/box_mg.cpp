@@ -4,7 +4,9 @@
 // The particle species that produce rho in the reference are replaced by the deterministic
 // synthetic charge density used by this repository's benchmarks.
 //
-//   box_mg [n=41] [depth=2] [tol=1e-4] [--dump file]   (--dump writes phi as raw fp64, [i][j][k])
+//   box_mg [n=41] [depth=2] [tol=1e-4] [--dump file] [--dump-ef file]
+//   depth 0 selects the plain Gauss-Seidel/SOR solver; --dump writes phi as raw fp64 [i][j][k],
+//   --dump-ef the electric field as raw fp64 [i][j][k][3]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -19,10 +21,11 @@ int main(int argc, char **argv)
 {
     int n = 41, depth = 2;
     double tol = 1e-4;
-    const char *dump = nullptr;
+    const char *dump = nullptr, *dump_ef = nullptr;
     int pos = 0;
     for (int a = 1; a < argc; a++) {
         if (!strcmp(argv[a], "--dump") && a + 1 < argc) dump = argv[++a];
+        else if (!strcmp(argv[a], "--dump-ef") && a + 1 < argc) dump_ef = argv[++a];
         else if (pos == 0) { n = atoi(argv[a]); pos++; }
         else if (pos == 1) { depth = atoi(argv[a]); pos++; }
         else if (pos == 2) { tol = atof(argv[a]); pos++; }
@@ -41,7 +44,8 @@ int main(int argc, char **argv)
                                          (std::sin(pi * x) * std::sin(pi * y) * std::sin(pi * z) +
                                           0.5 * std::sin(5 * pi * x) * std::sin(3 * pi * y) * std::sin(7 * pi * z));
                 }
-        MultiGridSolverHIP *mg = new MultiGridSolverHIP(world, 10000, tol, depth);
+        MultiGridSolverHIP *mg = depth == 0 ? new GaussSeidelSolverHIP(world, 100000, tol)
+                                            : new MultiGridSolverHIP(world, 10000, tol, depth);
         PotentialSolver *solver = mg;  // used through the base pointer, like the reference driver
         auto t0 = std::chrono::high_resolution_clock::now();
         const bool ok = solver->solve();
@@ -55,6 +59,14 @@ int main(int argc, char **argv)
             FILE *f = fopen(dump, "wb");
             if (!f || fwrite(world.phi.flat(), sizeof(double), world.phi.size(), f) != world.phi.size()) {
                 std::cerr << "cannot write " << dump << std::endl;
+                return 3;
+            }
+            fclose(f);
+        }
+        if (dump_ef) {
+            FILE *f = fopen(dump_ef, "wb");
+            if (!f || fwrite(world.ef.flat(), sizeof(double3), world.ef.size(), f) != world.ef.size()) {
+                std::cerr << "cannot write " << dump_ef << std::endl;
                 return 3;
             }
             fclose(f);

@@ -48,7 +48,8 @@ typedef struct mg_handle mg_handle;
  * constants of the reference classes:
  *   n, dh   World::ni,nj,nk and World::getDh()          (cpp/World.h:50,92)
  *   depth   number of coarse grids: 1 = MultiGridSolver, 2 = V2, ... 5 = V5
- *           (cpp/PotentialSolver.h:171-272); level l has n>>l nodes per axis
+ *           (cpp/PotentialSolver.h:171-272); level l has n>>l nodes per axis.
+ *           0 = no coarse grids: the handle serves mg_gs_solve / mg_compute_ef only
  *   nu      sweeps per level, nu[0] on the fine grid, nu[depth] on the coarsest
  *           (cpp/PotentialSolver.cpp:2422-2425, :2629-2634, :2922-2929,
  *            :3298-3307, :3759-3770)
@@ -83,6 +84,7 @@ typedef enum mg_timer_kind {
     MG_T_PROLONG,         /* coarse-to-coarse prolongations */
     MG_T_PROLONG_CORRECT, /* fine prolongation fused with phi -= eps */
     MG_T_NORM,            /* final reduction of the partial sums */
+    MG_T_EF,              /* electric field E = -grad(phi) */
     MG_T_COUNT
 } mg_timer_kind;
 
@@ -132,6 +134,22 @@ int mg_vcycle(mg_handle *h, double *L2);
 /* `count` iterations back to back with no host synchronisation in between;
  * *L2 = norm observed in the last one. */
 int mg_vcycles(mg_handle *h, unsigned count, double *L2);
+/* GaussSeidelSolver::solve() (cpp/PotentialSolver.cpp:235-291) on the fine grid
+ * with the red-black ordering: one SOR sweep per iteration; in iterations with
+ * it % 25 == 0 the norm sqrt(sum(R^2)/(ni*nj*nk)) of the residual over the
+ * INTERIOR nodes is tested against tol.  *iterations = sweeps performed, *L2 =
+ * last norm evaluated.  Works on any handle (depth 0 allocates no coarse grids). */
+int mg_gs_solve(mg_handle *h, unsigned max_it, double tol, int *converged,
+                unsigned *iterations, double *L2);
+
+/* PotentialSolver::computeEF() (cpp/PotentialSolver.cpp:418-458) on the
+ * device-resident phi: E = -grad(phi), central differences inside, 3-point
+ * one-sided differences on the faces.  The field stays on the device until
+ * mg_get_ef copies it out as [i][j][k][3] doubles (the layout of World::ef,
+ * Field_<double3>); it is invalidated by mg_set_phi and by the solve calls. */
+int mg_compute_ef(mg_handle *h);
+int mg_get_ef(mg_handle *h, double *ef_flat);
+
 /* Zero R_l and eps_l: the state of a freshly constructed reference solver
  * (cpp/Field.h:72).  The reference never does this after construction. */
 int mg_reset_state(mg_handle *h);
@@ -193,6 +211,10 @@ int mg_op_prolong_correct(int device, const int64_t n[3], const double *eps_coar
 int mg_op_smooth_rb(int device, const int64_t n[3], const int64_t u_dims[3],
                     const int64_t rhs_dims[3], const double c[3], double omega,
                     int sweeps, int rhs_is_rho, const double *rhs, double *u);
+/* E = -grad(phi) (cpp/PotentialSolver.cpp:418-458); ef receives
+ * n[0]*n[1]*n[2]*3 doubles, [i][j][k][component]. */
+int mg_op_compute_ef(int device, const int64_t n[3], const double dh[3],
+                     const double *phi, double *ef);
 /* sum of x[p]^2 (cpp/PotentialSolver.cpp:3810-3816) */
 int mg_op_sumsq(int device, int64_t count, const double *x, double *out);
 
@@ -246,6 +268,12 @@ int mg_dev_restrict27(void *stream, const mg_dev_array *Rf, const mg_dev_array *
  * out -= P(ec) (correct != 0, out = phi); n = size of the fine level.  Reads ec planes [lo/2, (hi-1)/2 + 2). */
 int mg_dev_prolong(void *stream, const mg_dev_array *ec, const mg_dev_array *out,
                    const int64_t n[3], int64_t lo, int64_t hi, int correct);
+
+/* Planes [lo,hi) of E = -grad(phi) (cpp/PotentialSolver.cpp:418-458).  ef is a dense device
+ * array [plane][nj][nk][3] whose plane 0 is global plane ef_i0 (no row padding).  Reads phi
+ * planes [lo-1, hi+1), plus plane 2 when lo == 0 and plane n-3 when hi == n. */
+int mg_dev_compute_ef(void *stream, const mg_dev_array *phi, void *ef, int64_t ef_i0,
+                      const int64_t n[3], const double dh[3], int64_t lo, int64_t hi);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,8 @@ struct mg_handle {
     Level lv[MG_MAX_LEVELS];
     View phi, b;            // fine potential and rho/EPS_0
     View phi_alt;           // ping-pong twin of phi for the out-of-place fused sweep
+    double *ef = nullptr;       // E field, dense [i][j][k][3]; allocated by the first mg_compute_ef
+    bool have_ef = false;
     double *partials = nullptr;
     int64_t n_partials = 0;
     double *d_sum = nullptr;    // device scalar: sum of R_h^2
@@ -246,9 +248,10 @@ double l2_from_sum(const mg_handle *h, double sum)
     return std::sqrt(sum / (double)count3(h->lv[0].n));
 }
 
-int check_ready(mg_handle *h)
+int check_ready(mg_handle *h, bool multigrid = true)
 {
     if (!h) return fail(MG_ERR_INVALID, "null handle");
+    if (multigrid && h->L < 1) return fail(MG_ERR_STATE, "the handle was created with depth 0 (no coarse grids)");
     if (!h->have_rho || !h->have_phi)
         return fail(MG_ERR_STATE, "mg_set_rho and mg_set_phi must be called before solving");
     HIP_TRY(hipSetDevice(h->cfg.device));
@@ -302,7 +305,7 @@ int mg_device_count(void)
 int mg_default_config(mg_config *cfg, int64_t ni, int64_t nj, int64_t nk, const double dh[3], int depth)
 {
     if (!cfg || !dh) return fail(MG_ERR_INVALID, "null argument");
-    if (depth < 1 || depth >= MG_MAX_LEVELS) return fail(MG_ERR_INVALID, "depth %d out of range 1..%d", depth, MG_MAX_LEVELS - 1);
+    if (depth < 0 || depth >= MG_MAX_LEVELS) return fail(MG_ERR_INVALID, "depth %d out of range 0..%d", depth, MG_MAX_LEVELS - 1);
     memset(cfg, 0, sizeof(*cfg));
     cfg->n[0] = ni;
     cfg->n[1] = nj;
@@ -314,7 +317,7 @@ int mg_default_config(mg_config *cfg, int64_t ni, int64_t nj, int64_t nk, const 
     // 50 on the coarsest (reference cpp/PotentialSolver.cpp:2422-2425 ... :3759-3770)
     cfg->nu[0] = depth >= 5 ? 1 : 3;
     for (int l = 1; l < depth; l++) cfg->nu[l] = 5;
-    cfg->nu[depth] = 50;
+    if (depth >= 1) cfg->nu[depth] = 50;
     return MG_OK;
 }
 
@@ -323,7 +326,7 @@ int mg_create(const mg_config *cfg, mg_handle **out)
     if (!cfg || !out) return fail(MG_ERR_INVALID, "null argument");
     *out = nullptr;
     const int L = cfg->depth;
-    if (L < 1 || L >= MG_MAX_LEVELS) return fail(MG_ERR_INVALID, "depth %d out of range 1..%d", L, MG_MAX_LEVELS - 1);
+    if (L < 0 || L >= MG_MAX_LEVELS) return fail(MG_ERR_INVALID, "depth %d out of range 0..%d", L, MG_MAX_LEVELS - 1);
     for (int a = 0; a < 3; a++) {
         if (cfg->n[a] < 3 || cfg->n[a] > (int64_t)1 << 20) return fail(MG_ERR_INVALID, "n[%d]=%lld out of range", a, (long long)cfg->n[a]);
         if ((cfg->n[a] >> L) < 3) return fail(MG_ERR_INVALID, "n[%d]=%lld too small for depth %d (coarsest level needs >= 3 nodes)", a, (long long)cfg->n[a], L);
@@ -338,7 +341,7 @@ int mg_create(const mg_config *cfg, mg_handle **out)
     if (!h) return fail(MG_ERR_NOMEM, "host allocation failed");
     h->cfg = *cfg;
     h->L = L;
-    h->fused_residual = !(cfg->flags & MG_FLAG_KEEP_FINE_RESIDUAL);
+    h->fused_residual = L >= 1 && !(cfg->flags & MG_FLAG_KEEP_FINE_RESIDUAL);
     if (getenv("MG_KEEP_RF")) h->fused_residual = false;  // A/B measurements
     memset(&h->timers, 0, sizeof(h->timers));
     memset(h->lv, 0, sizeof(h->lv));
@@ -380,6 +383,8 @@ int mg_create(const mg_config *cfg, mg_handle **out)
         const IRange all{0, h->lv[0].n[0]};
         h->n_partials = h->fused_residual ? mgk::residual_restrict_partials(h->lv[0].n, all)
                                           : mgk::residual_partials(h->lv[0].n, all);
+        const int64_t gs = mgk::gs_residual_partials(h->lv[0].n, all);
+        if (gs > h->n_partials) h->n_partials = gs;
     }
     CREATE_TRY(hip_try(hipMalloc((void **)&h->partials, (size_t)h->n_partials * sizeof(double)), "hipMalloc(partials)"));
     CREATE_TRY(hip_try(hipMalloc((void **)&h->d_sum, sizeof(double)), "hipMalloc(sum)"));
@@ -405,6 +410,7 @@ int mg_destroy(mg_handle *h)
     if (h->phi.p) hipFree(h->phi.p);
     if (h->phi_alt.p) hipFree(h->phi_alt.p);
     if (h->b.p) hipFree(h->b.p);
+    if (h->ef) hipFree(h->ef);
     if (h->partials) hipFree(h->partials);
     if (h->d_sum) hipFree(h->d_sum);
     if (h->h_sum) hipHostFree(h->h_sum);
@@ -432,6 +438,7 @@ int mg_set_phi(mg_handle *h, const double *phi_flat)
     int rc = upload(h, phi_flat, h->phi, false);
     if (rc) return rc;
     h->have_phi = true;
+    h->have_ef = false;
     return MG_OK;
 }
 
@@ -453,6 +460,7 @@ int mg_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsigned
     bool conv = false;
     double l2 = 0;
     unsigned it = 0;
+    h->have_ef = false;
     HIP_TRY(hipEventRecord(h->ev_a, h->stream));
     for (it = 0; it < max_it; it++) {
         enqueue_smooth_residual(h);
@@ -483,6 +491,7 @@ int mg_vcycles(mg_handle *h, unsigned count, double *L2)
 {
     int rc = check_ready(h);
     if (rc) return rc;
+    h->have_ef = false;
     HIP_TRY(hipEventRecord(h->ev_a, h->stream));
     for (unsigned it = 0; it < count; it++) {
         enqueue_smooth_residual(h);
@@ -500,6 +509,90 @@ int mg_vcycles(mg_handle *h, unsigned count, double *L2)
 }
 
 int mg_vcycle(mg_handle *h, double *L2) { return mg_vcycles(h, 1, L2); }
+
+int mg_gs_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsigned *iterations, double *L2)
+{
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    Level &f = h->lv[0];
+    const double N = (double)count3(f.n);
+    const IRange all{0, f.n[0]};
+    const int64_t np = mgk::gs_residual_partials(f.n, all);
+    bool conv = false;
+    double l2 = 0;
+    unsigned it = 0;
+    h->have_ef = false;
+    HIP_TRY(hipEventRecord(h->ev_a, h->stream));
+    for (it = 0; it < max_it; it++) {
+        {
+            Prof p(h, MG_T_SMOOTH_FINE, 32.0 * N);
+            p.launches = mgk::smooth_rb(h->stream, &h->phi, &h->phi_alt, h->b, f.n, f.c, h->cfg.omega, 1, all);
+        }
+        if (it % 25 == 0) {  // cpp/PotentialSolver.cpp:268
+            {
+                Prof p(h, MG_T_RESIDUAL, 16.0 * N);
+                mgk::gs_residual_sumsq(h->stream, h->phi, h->b, f.n, f.c, h->partials, all);
+            }
+            {
+                Prof p(h, MG_T_NORM, 8.0 * (double)np);
+                mgk::sum_partials(h->stream, h->partials, np, h->d_sum);
+            }
+            HIP_TRY(hipMemcpyAsync(h->h_sum, h->d_sum, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            l2 = l2_from_sum(h, *h->h_sum);
+            if (l2 < tol) {
+                conv = true;
+                it++;
+                break;
+            }
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_b, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    h->last_ms = ms;
+    if (converged) *converged = conv ? 1 : 0;
+    if (iterations) *iterations = it;
+    if (L2) *L2 = l2;
+    return MG_OK;
+}
+
+int mg_compute_ef(mg_handle *h)
+{
+    if (!h) return fail(MG_ERR_INVALID, "null handle");
+    if (!h->have_phi) return fail(MG_ERR_STATE, "no phi on the device yet");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int64_t *n = h->lv[0].n;
+    if (!h->ef) HIP_TRY(hipMalloc((void **)&h->ef, (size_t)count3(n) * 3 * sizeof(double)));
+    flush_correction(h);
+    HIP_TRY(hipEventRecord(h->ev_a, h->stream));
+    {
+        Prof p(h, MG_T_EF, 32.0 * (double)count3(n));
+        mgk::compute_ef(h->stream, h->phi, h->ef, 0, n, h->cfg.dh, IRange{0, n[0]});
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_b, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    h->last_ms = ms;
+    h->have_ef = true;
+    return MG_OK;
+}
+
+int mg_get_ef(mg_handle *h, double *ef_flat)
+{
+    if (!h || !ef_flat) return fail(MG_ERR_INVALID, "null argument");
+    if (!h->have_ef) return fail(MG_ERR_STATE, "mg_compute_ef has not run on the current phi");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipMemcpyAsync(ef_flat, h->ef, (size_t)count3(h->lv[0].n) * 3 * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MG_OK;
+}
 
 int mg_reset_state(mg_handle *h)
 {
@@ -773,6 +866,25 @@ int mg_op_smooth_rb(int device, const int64_t n[3], const int64_t u_dims[3], con
     return sc.download(vu, u);
 }
 
+int mg_op_compute_ef(int device, const int64_t n[3], const double dh[3], const double *phi, double *ef)
+{
+    if (!dh || !phi || !ef) return fail(MG_ERR_INVALID, "null argument");
+    TRY(check_dims(n, "mg_op_compute_ef", 3));
+    for (int a = 0; a < 3; a++)
+        if (!(dh[a] > 0)) return fail(MG_ERR_INVALID, "mg_op_compute_ef: dh[%d] must be positive", a);
+    TRY(select_device(device));
+    Scratch sc;
+    View vphi;
+    TRY(sc.view(&vphi, n, phi));
+    double *def = nullptr;
+    const int64_t count = count3(n) * 3;
+    TRY(sc.flat(&def, count, nullptr));
+    mgk::compute_ef(nullptr, vphi, def, 0, n, dh, IRange{0, n[0]});
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(ef, def, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    return MG_OK;
+}
+
 int mg_op_sumsq(int device, int64_t count, const double *x, double *out)
 {
     if (!x || !out || count < 0) return fail(MG_ERR_INVALID, "bad argument");
@@ -938,6 +1050,25 @@ int mg_dev_prolong(void *stream, const mg_dev_array *ec, const mg_dev_array *out
     }
     if (correct) mgk::prolong_correct((hipStream_t)stream, vc, vo, n, IRange{lo, hi});
     else mgk::prolong((hipStream_t)stream, vc, vo, n, IRange{lo, hi});
+    HIP_TRY(hipGetLastError());
+    return MG_OK;
+}
+
+int mg_dev_compute_ef(void *stream, const mg_dev_array *phi, void *ef, int64_t ef_i0, const int64_t n[3],
+                      const double dh[3], int64_t lo, int64_t hi)
+{
+    if (!n || !dh || !ef) return fail(MG_ERR_INVALID, "null argument");
+    View vp;
+    TRY(dev_view(phi, &vp, "mg_dev_compute_ef(phi)"));
+    if (n[0] < 3 || n[1] < 3 || n[2] < 3 || vp.d[1] != n[1] || vp.d[2] != n[2])
+        return fail(MG_ERR_INVALID, "mg_dev_compute_ef: phi rows/columns must match n (>= 3 per axis)");
+    if (lo < 0 || hi > n[0] || lo > hi || ef_i0 > lo) return fail(MG_ERR_INVALID, "mg_dev_compute_ef: bad plane range");
+    if (lo < hi) {
+        TRY(need_planes(vp, lo - 1, hi + 1, n[0], "mg_dev_compute_ef(phi)"));
+        if (lo == 0) TRY(need_planes(vp, 0, 3, n[0], "mg_dev_compute_ef(phi)"));
+        if (hi == n[0]) TRY(need_planes(vp, n[0] - 3, n[0], n[0], "mg_dev_compute_ef(phi)"));
+    }
+    mgk::compute_ef((hipStream_t)stream, vp, (double *)ef, ef_i0, n, dh, IRange{lo, hi});
     HIP_TRY(hipGetLastError());
     return MG_OK;
 }

@@ -79,6 +79,28 @@ __device__ __forceinline__ double div_d(double x, const Coef &c)
     const double q1 = fma(fma(-q0, c.d, x), c.rd, q0);
     return fma(fma(-q1, c.d, x), c.rd, q1);
 }
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum over a workgroup of up to 1024 threads; result valid in thread 0.
+// Fixed order: lanes by shuffle tree, then waves 0..nw-1 left to right.
+__device__ __forceinline__ double block_sum(double v, double *lds)
+{
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+    v = wave_sum(v);
+    if ((tid & 63) == 0) lds[tid >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    if (tid == 0)
+        for (int w = 0; w < nw; w++) t += lds[w];
+    return t;
+}
 #endif
 
 // v = v / EPS_0 in place over the whole view: turns an uploaded rho into the rhs b.
@@ -129,5 +151,17 @@ void prolong(hipStream_t s, View ec, View ef, const int64_t n[3], IRange r);
 // phi -= prolong(ec) on planes r (within 1..n-2 per axis)
 void prolong_correct(hipStream_t s, View ec, View phi, const int64_t n[3], IRange r);
 void correct(hipStream_t s, double *phi, const double *eps, int64_t count);
+
+// E = -grad(phi) for planes r (reference cpp/PotentialSolver.cpp:418-458).  ef is dense
+// [plane][nj][nk][3] and its plane 0 is global plane ef_i0.  phi must hold planes
+// [r.lo-1, r.hi+1) as far as they exist, plane 2 when r contains plane 0 and plane n-3 when r
+// contains plane n-1.
+void compute_ef(hipStream_t s, View phi, double *ef, int64_t ef_i0, const int64_t n[3], const double dh[3],
+                IRange r);
+// Residual of GaussSeidelSolver's convergence test (reference cpp/PotentialSolver.cpp:270-282):
+// per-workgroup partial sums of R^2 over the interior points of planes r,
+// R = -phi*d + b + cx*(..) + cy*(..) + cz*(..).
+int64_t gs_residual_partials(const int64_t n[3], IRange r);
+void gs_residual_sumsq(hipStream_t s, View phi, View b, const int64_t n[3], Coef c, double *partials, IRange r);
 
 }  // namespace mgk

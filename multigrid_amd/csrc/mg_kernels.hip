@@ -19,28 +19,6 @@ constexpr int kBX = 64;  // lanes along k
 constexpr int kBY = 4;   // rows along j per workgroup
 constexpr int kLdsSmoothMaxBytes = 128 * 1024;  // u + rhs of a level handled by k_smooth_lds
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// Sum over a workgroup of up to 1024 threads; result valid in thread 0.
-// Fixed order: lanes by shuffle tree, then waves 0..nw-1 left to right.
-__device__ __forceinline__ double block_sum(double v, double *lds)
-{
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    const int nw = (blockDim.x * blockDim.y + 63) >> 6;
-    v = wave_sum(v);
-    if ((tid & 63) == 0) lds[tid >> 6] = v;
-    __syncthreads();
-    double t = 0;
-    if (tid == 0)
-        for (int w = 0; w < nw; w++) t += lds[w];
-    return t;
-}
-
 __global__ __launch_bounds__(256) void k_div_eps0(View v)
 {
     const int64_t k = (int64_t)blockIdx.x * kBX + threadIdx.x;

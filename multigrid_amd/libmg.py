@@ -17,7 +17,7 @@ MG_ABI_VERSION = 1
 MG_FLAG_KEEP_FINE_RESIDUAL = 1
 
 TIMER_KINDS = ("smooth_fine", "residual", "restrict", "smooth_coarse", "prolong",
-               "prolong_correct", "norm")
+               "prolong_correct", "norm", "ef")
 
 _i64x3 = C.c_int64 * 3
 _f64x3 = C.c_double * 3
@@ -63,6 +63,9 @@ SYMBOLS = {
     "mg_solve": (C.c_int, [_H, C.c_uint, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_uint), _dp]),
     "mg_vcycle": (C.c_int, [_H, _dp]),
     "mg_vcycles": (C.c_int, [_H, C.c_uint, _dp]),
+    "mg_gs_solve": (C.c_int, [_H, C.c_uint, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_uint), _dp]),
+    "mg_compute_ef": (C.c_int, [_H]),
+    "mg_get_ef": (C.c_int, [_H, _dp]),
     "mg_reset_state": (C.c_int, [_H]),
     "mg_get_level_array": (C.c_int, [_H, C.c_int, C.c_int, _dp, _i64x3]),
     "mg_set_profiling": (C.c_int, [_H, C.c_int]),
@@ -76,6 +79,7 @@ SYMBOLS = {
     "mg_op_correct": (C.c_int, [C.c_int, C.c_int64, _dp, _dp]),
     "mg_op_prolong_correct": (C.c_int, [C.c_int, _i64x3, _dp, _dp]),
     "mg_op_smooth_rb": (C.c_int, [C.c_int, _i64x3, _i64x3, _i64x3, _f64x3, C.c_double, C.c_int, C.c_int, _dp, _dp]),
+    "mg_op_compute_ef": (C.c_int, [C.c_int, _i64x3, _f64x3, _dp, _dp]),
     "mg_op_sumsq": (C.c_int, [C.c_int, C.c_int64, _dp, _dp]),
     # device-level operators of the slab-partitioned solve (multigrid_amd/dist.py)
     "mg_dev_pitch": (C.c_int64, [C.c_int64]),
@@ -92,6 +96,8 @@ SYMBOLS = {
                                     C.c_int64, C.c_int64]),
     "mg_dev_prolong": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.POINTER(MgDevArray), _i64x3, C.c_int64,
                                  C.c_int64, C.c_int]),
+    "mg_dev_compute_ef": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.c_void_p, C.c_int64, _i64x3, _f64x3,
+                                    C.c_int64, C.c_int64]),
 }
 
 _lib = None
@@ -200,6 +206,22 @@ class Handle:
         _check(load().mg_vcycles(self._h, count, C.byref(l2)))
         return l2.value
 
+    def gs_solve(self, max_it=10000, tol=1e-4):
+        """Plain red-black GS-SOR (the reference's GaussSeidelSolver loop). Returns (converged, sweeps, L2)."""
+        conv, its, l2 = C.c_int(0), C.c_uint(0), C.c_double(0)
+        _check(load().mg_gs_solve(self._h, max_it, tol, C.byref(conv), C.byref(its), C.byref(l2)))
+        return bool(conv.value), its.value, l2.value
+
+    def compute_ef(self, download=True):
+        """E = -grad(phi) on the device; returns the (ni,nj,nk,3) array unless download is False."""
+        _check(load().mg_compute_ef(self._h))
+        return self.get_ef() if download else None
+
+    def get_ef(self):
+        out = np.empty(self.n + (3,))
+        _check(load().mg_get_ef(self._h, _out(out)))
+        return out
+
     def reset_state(self):
         _check(load().mg_reset_state(self._h))
 
@@ -290,6 +312,13 @@ def op_smooth_rb(u, rhs, n, c, omega=1.4, sweeps=1, rhs_is_rho=False, device=0):
     _check(load().mg_op_smooth_rb(device, _i64x3(*n), _i64x3(*u.shape), _i64x3(*rhs.shape),
                                   _f64x3(*c[:3]), omega, sweeps, int(rhs_is_rho), pr, _out(u)))
     return u
+
+
+def op_compute_ef(phi, dh, device=0):
+    phi, pp = _in(phi)
+    ef = np.empty(phi.shape + (3,))
+    _check(load().mg_op_compute_ef(device, _i64x3(*phi.shape), _f64x3(*dh), pp, _out(ef)))
+    return ef
 
 
 def op_sumsq(x, device=0):

@@ -229,6 +229,44 @@ void orc_compute_ef(const double *phi, double *ef, const int64_t n[3], const dou
             }
 }
 
+/* GaussSeidelSolver::solve (cpp/PotentialSolver.cpp:235-291): one SOR sweep per iteration
+ * (lexicographic as the reference, or red-black when rb); in iterations with it%25 == 0 the
+ * norm sqrt(sum/(ni*nj*nk)) of R = -phi*d + rho/EPS_0 + cx*(..) + cy*(..) + cz*(..) summed over
+ * the INTERIOR nodes in i,j,k order is tested (:268-286).  Returns converged; *iterations =
+ * sweeps performed, *l2_out = last norm evaluated. */
+int orc_gs_solve(double *phi, const double *rho, const int64_t n[3], const double dh[3],
+                 unsigned max_it, double tol, double omega, int rb, unsigned *iterations, double *l2_out)
+{
+    const int64_t ni = n[0], nj = n[1], nk = n[2], si = nj * nk, sj = nk;
+    double c[4];
+    orc_coeffs(dh, 0, c);
+    double L2 = 0;
+    int converged = 0;
+    unsigned it;
+    for (it = 0; it < max_it; it++) {
+        if (rb) orc_smooth_rb(phi, n, rho, n, n, c, omega, 1, 1);
+        else orc_smooth_lex(phi, n, rho, n, n, c, omega, 1, 1);
+        if (it % 25 == 0) {
+            double sum = 0;
+            for (int64_t i = 1; i < ni - 1; i++)
+                for (int64_t j = 1; j < nj - 1; j++)
+                    for (int64_t k = 1; k < nk - 1; k++) {
+                        int64_t p = IDX(i, j, k, nj, nk);
+                        double R = -phi[p] * c[3] + rho[p] / ORC_EPS_0 +
+                                   c[0] * (phi[p - si] + phi[p + si]) +
+                                   c[1] * (phi[p - sj] + phi[p + sj]) +
+                                   c[2] * (phi[p - 1] + phi[p + 1]);
+                        sum += R * R;
+                    }
+            L2 = sqrt(sum / (double)(ni * nj * nk));
+            if (L2 < tol) { converged = 1; it++; break; }
+        }
+    }
+    if (iterations) *iterations = it;
+    if (l2_out) *l2_out = L2;
+    return converged;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Whole solver: the state the reference keeps in class members
  * (cpp/PotentialSolver.h:171-272): R_l (n_l^3), eps_0 (n_0^3), eps_l ((n_l+1)^3),

@@ -91,6 +91,9 @@ def lib():
         L.orc_solve.argtypes = [C.c_void_p, _dp, _dp, C.c_uint, C.c_double, C.c_int,
                                 C.POINTER(C.c_uint), _dp, _dp]
         L.orc_solve.restype = C.c_int
+        L.orc_gs_solve.argtypes = [_dp, _dp, _i64x3, _f64x3, C.c_uint, C.c_double, C.c_double, C.c_int,
+                                   C.POINTER(C.c_uint), _dp]
+        L.orc_gs_solve.restype = C.c_int
         V = C.POINTER(OrcView)
         L.orc_slab_smooth_rb.argtypes = [V, V, _i64x3, _f64x4, C.c_double, C.c_int64, C.c_int64]
         L.orc_slab_smooth_rb.restype = None
@@ -169,6 +172,15 @@ def compute_ef(phi, dh):
     ef = np.empty(phi.shape + (3,))
     lib().orc_compute_ef(_p(phi), _p(ef), _dims(phi), _f64x3(*dh))
     return ef
+
+
+def gs_solve(phi, rho, dh, max_it=10000, tol=1e-4, omega=1.4, rb=False):
+    """The reference's GaussSeidelSolver loop in place on phi. Returns (converged, sweeps, L2)."""
+    its = C.c_uint(0)
+    l2 = C.c_double(0)
+    ok = lib().orc_gs_solve(_p(phi), _p(rho), _dims(phi), _f64x3(*dh), max_it, tol, omega, int(rb),
+                            C.byref(its), C.byref(l2))
+    return bool(ok), its.value, l2.value
 
 
 SCHEDULES = {  # nu[0..L] of the reference classes (cpp/PotentialSolver.cpp:2422-2425,

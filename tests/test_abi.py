@@ -42,7 +42,8 @@ def test_default_config_matches_reference_schedules(mg):
 
 def test_bad_arguments_are_rejected(mg):
     with pytest.raises(mg.MgError):
-        mg.default_config((41, 41, 41), (1e-2,) * 3, 0)
+        mg.default_config((41, 41, 41), (1e-2,) * 3, -1)
+    assert mg.default_config((41, 41, 41), (1e-2,) * 3, 0).depth == 0  # Gauss-Seidel / field-only handle
     with pytest.raises(mg.MgError):
         mg.default_config((41, 41, 41), (1e-2,) * 3, mg.MG_MAX_LEVELS)
 
@@ -59,3 +60,5 @@ def test_no_silent_cpu_fallback(mg):
         mg.op_sumsq(np.ones(8))
     with pytest.raises(mg.MgError):
         mg.op_residual(np.zeros((5, 5, 5)), np.zeros((5, 5, 5)), (1e-2,) * 3)
+    with pytest.raises(mg.MgError):
+        mg.op_compute_ef(np.zeros((5, 5, 5)), (1e-2,) * 3)

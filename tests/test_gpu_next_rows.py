@@ -1,0 +1,93 @@
+"""Parity of the rows next to the V-cycle: the electric field E = -grad(phi)
+(reference PotentialSolver::computeEF, cpp/PotentialSolver.cpp:418-458) and the plain
+Gauss-Seidel/SOR solver (GaussSeidelSolver::solve, cpp/PotentialSolver.cpp:235-291), both
+through the C ABI against the CPU oracle.  Bit equality for the fields; the norm is a tree sum
+on the GPU and a sequential one in the oracle (relative tolerance 1e-11, as for the V-cycle)."""
+import numpy as np
+import pytest
+
+from util import assert_bit_equal, phi_like, rel_l2, rng
+
+pytestmark = pytest.mark.gpu
+
+EF_SHAPES = [(3, 3, 3), (4, 5, 6), (17, 17, 17), (20, 20, 20), (33, 21, 45), (41, 41, 41),
+             (64, 64, 64), (65, 65, 65), (5, 200, 129), (129, 129, 129)]
+
+
+@pytest.mark.parametrize("shape", EF_SHAPES, ids=str)
+def test_compute_ef_operator(gpu, orc, shape):
+    phi = phi_like(shape, rng(21))
+    dh = (0.4 / (shape[0] - 1), 0.37 / (shape[1] - 1), 0.41 / (shape[2] - 1))
+    assert_bit_equal(gpu.op_compute_ef(phi, dh), orc.compute_ef(phi, dh), "ef")
+
+
+def test_compute_ef_on_the_handle_follows_the_solve(gpu, orc):
+    """mg_compute_ef works on the device-resident phi a solve left behind."""
+    N = (41, 41, 41)
+    dh, rho = orc.main_extents_dh(N), orc.synthetic_rho(N)
+    with gpu.Handle(N, dh, 2) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        with pytest.raises(gpu.MgError):   # nothing computed yet
+            h.get_ef()
+        h.vcycles(3)                       # leaves through the pending-correction path
+        ef = h.compute_ef()
+        phi = h.get_phi()
+        assert_bit_equal(ef, orc.compute_ef(phi, dh), "ef after cycles")
+        h.solve(100, 1e-6)
+        with pytest.raises(gpu.MgError):   # stale after a solve
+            h.get_ef()
+        assert_bit_equal(h.compute_ef(), orc.compute_ef(h.get_phi(), dh), "ef after solve")
+
+
+@pytest.mark.parametrize("n,max_it", [((17, 17, 17), 60), ((41, 41, 41), 130), ((33, 21, 45), 77),
+                                      ((129, 129, 129), 30), ((140, 150, 160), 27)], ids=str)
+def test_gs_sweeps_match_rb_oracle_bit_for_bit(gpu, orc, n, max_it):
+    dh, rho = orc.main_extents_dh(n), orc.synthetic_rho(n)
+    want = np.zeros(n)
+    w_ok, w_it, w_l2 = orc.gs_solve(want, rho, dh, max_it, 0.0, rb=True)
+    with gpu.Handle(n, dh, 0) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(n))
+        ok, its, l2 = h.gs_solve(max_it, 0.0)
+        got = h.get_phi()
+    assert (ok, its) == (w_ok, w_it) == (False, max_it)
+    assert_bit_equal(got, want, "GS phi")
+    assert l2 == pytest.approx(w_l2, rel=1e-11)
+
+
+def test_gs_converges_like_the_reference_loop(gpu, orc):
+    """Same stopping rule (test every 25th sweep, interior-only norm); the red-black iterate
+    converges to the same discrete solution as the reference's lexicographic loop."""
+    n = (33, 33, 33)
+    dh, rho = orc.main_extents_dh(n), orc.synthetic_rho(n)
+    lex = np.zeros(n)
+    l_ok, l_it, _ = orc.gs_solve(lex, rho, dh, 20000, 1e-6, rb=False)
+    twin = np.zeros(n)
+    t_ok, t_it, t_l2 = orc.gs_solve(twin, rho, dh, 20000, 1e-6, rb=True)
+    with gpu.Handle(n, dh, 0) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(n))
+        ok, its, l2 = h.gs_solve(20000, 1e-6)
+        got = h.get_phi()
+        with pytest.raises(gpu.MgError):   # depth 0: no V-cycle on this handle
+            h.solve(1, 1e-6)
+    assert l_ok and t_ok and ok
+    assert its == t_it and its % 25 == 1     # converged in a tested iteration
+    assert_bit_equal(got, twin, "GS converged phi")
+    assert l2 == pytest.approx(t_l2, rel=1e-11)
+    assert rel_l2(got, lex) < 1e-6
+
+
+def test_gs_on_a_multigrid_handle(gpu, orc):
+    """mg_gs_solve shares phi/rho with the V-cycle handle (the reference's MG classes derive
+    from GaussSeidelSolver)."""
+    n = (41, 41, 41)
+    dh, rho = orc.main_extents_dh(n), orc.synthetic_rho(n)
+    want = np.zeros(n)
+    orc.gs_solve(want, rho, dh, 10, 0.0, rb=True)
+    with gpu.Handle(n, dh, 2) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(n))
+        h.gs_solve(10, 0.0)
+        assert_bit_equal(h.get_phi(), want, "GS on MG handle")

@@ -49,3 +49,23 @@ def test_solve_through_potential_solver_interface(box, gpu, orc, tmp_path, n, de
     assert rel_l2(phi, phi_rb) <= 1e-9
     assert rel_l2(phi, phi_lex) <= 1e-6
     assert not phi[0].any() and not phi[:, :, -1].any()  # Dirichlet faces untouched
+
+
+@pytest.mark.gpu
+def test_gauss_seidel_and_field_through_the_interface(box, gpu, orc, tmp_path):
+    """depth 0 = GaussSeidelSolver behind the same base pointer; computeEF() is answered from the
+    device-resident potential and must equal the host formula applied to the returned phi."""
+    n = 33
+    out, out_ef = tmp_path / "phi.bin", tmp_path / "ef.bin"
+    p = subprocess.run([box, str(n), "0", "1e-6", "--dump", str(out), "--dump-ef", str(out_ef)],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "converged=1" in p.stdout
+    N = (n, n, n)
+    dh = orc.main_extents_dh(N)
+    phi = np.fromfile(out).reshape(N)
+    ef = np.fromfile(out_ef).reshape(N + (3,))
+    assert_bit_equal(ef, orc.compute_ef(phi, dh), "E from the device-resident phi")
+    lex = np.zeros(N)
+    assert orc.gs_solve(lex, orc.synthetic_rho(N), dh, 100000, 1e-6)[0]
+    assert rel_l2(phi, lex) <= 1e-6

@@ -40,3 +40,36 @@ def test_l2_history_matches_reference_record(orc, case, max_it):
         # the reference breaks in iteration index `converged_at`
         assert cycles == case["converged_at"] + 1
         assert l2 < 1e-6
+
+
+def test_compute_ef_is_exact_for_quadratics(orc):
+    """Central and 3-point one-sided differences are exact for a quadratic potential, so
+    E = -grad(phi) must come out analytically on every node, faces included
+    (cpp/PotentialSolver.cpp:418-458)."""
+    import numpy as np
+    n = (9, 12, 7)
+    dh = (0.05, 0.03, 0.07)
+    x = np.arange(n[0])[:, None, None] * dh[0]
+    y = np.arange(n[1])[None, :, None] * dh[1]
+    z = np.arange(n[2])[None, None, :] * dh[2]
+    phi = np.ascontiguousarray(3 * x * x - 2 * y * y + 0.5 * z * z + x * y - 4 * z + 1 + 0 * (x + y + z))
+    ef = orc.compute_ef(phi, dh)
+    want = np.stack(np.broadcast_arrays(-(6 * x + y), -(-4 * y + x), -(z - 4 + 0 * x)), axis=-1)
+    assert np.allclose(ef, want, rtol=0, atol=1e-11)
+
+
+def test_gs_loop_stops_on_a_tested_iteration_and_agrees_with_multigrid(orc):
+    """The reference's GaussSeidelSolver tests convergence only when it % 25 == 0
+    (cpp/PotentialSolver.cpp:268); its fixed point is the V-cycle's fixed point."""
+    import numpy as np
+    n = (21, 21, 21)
+    dh, rho = orc.main_extents_dh(n), orc.synthetic_rho(n)
+    gs = np.zeros(n)
+    ok, its, l2 = orc.gs_solve(gs, rho, dh, 20000, 1e-7)
+    assert ok and l2 < 1e-7 and its % 25 == 1
+    mg = np.zeros(n)
+    assert orc.Solver(n, dh, 1).solve(mg, rho, 500, 1e-7)[0]
+    assert np.linalg.norm(gs - mg) / np.linalg.norm(mg) < 1e-7
+    rb = np.zeros(n)
+    ok_rb, its_rb, _ = orc.gs_solve(rb, rho, dh, 20000, 1e-7, rb=True)
+    assert ok_rb and np.linalg.norm(rb - gs) / np.linalg.norm(gs) < 1e-7
