@@ -153,6 +153,25 @@ def run_single(args):
         ok, cycles, l2s = h.solve(10000, args.tol)
         dt = time.perf_counter() - t0
         solve = {"tol": args.tol, "converged": ok, "cycles": cycles, "seconds": dt, "L2": l2s}
+
+    # the rows either side of the V-cycle, on the same device-resident fields (not part of `value`):
+    # E = -grad(phi) (read 8 + write 24 B/pt), one plain red-black SOR sweep of the Gauss-Seidel
+    # solver (32 B/pt), and the host<->device transfers of one solve() through pageable memory
+    extras = {}
+    h.compute_ef(download=False)
+    ef_ms = min(h.compute_ef(download=False) or h.last_call_ms() for _ in range(3))
+    extras["compute_ef"] = {"ms": ef_ms, "GBps": 32.0 * npts / (ef_ms * 1e-3) / 1e9}
+    h.gs_solve(2, 0.0)
+    h.gs_solve(26, 0.0)
+    extras["gs_26_sweeps_2_norms_ms"] = h.last_call_ms()
+    t0 = time.perf_counter()
+    h.set_rho(rho)
+    h.set_phi(np.zeros(N))
+    buf = h.get_phi()
+    dt = time.perf_counter() - t0
+    extras["host_transfers"] = {"seconds": dt, "GBps": 3 * 8.0 * npts / dt / 1e9,
+                                "what": "mg_set_rho + mg_set_phi + mg_get_phi, pageable host arrays"}
+    del buf
     h.close()
 
     cpu = cpu_baseline(n, depth, args.cpu_cycles) if args.cpu_cycles > 0 else None
@@ -164,7 +183,8 @@ def run_single(args):
            "config": {"workload": f"{n}^3 fp64 multigrid V{depth} cycle (sweeps {list(h.cfg.nu[:depth + 1])}, omega 1.4), "
                                   f"red-black GS-SOR, 1 GPU", "grid": n, "depth": depth},
            "vcycles_per_s": vps, "device_ms_per_step": dev_ms / args.steps, "last_L2": l2,
-           "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "solve": solve}
+           "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "solve": solve,
+           "next_rows": extras}
     if cpu:
         out["speedup_vs_cpu_per_cycle"] = cpu["s_per_cycle"] / (wall / args.steps)
     print(json.dumps(out))

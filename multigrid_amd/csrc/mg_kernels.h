@@ -71,10 +71,16 @@ Coef make_coef(double cx, double cy, double cz, double d);
 // second-order terms) of x/d, hence a faithful rounding; its residual r1 = x - q1*d is then exact
 // in one FMA, and Markstein's theorem (the reciprocal is correctly rounded, the significand of d
 // is not all ones -- checked on the host) makes fma(r1, rd, q1) the correctly rounded quotient.
-// Explicit fma() calls are not contractions: -ffp-contract=off does not affect them.
+// The argument needs every intermediate to stay in the normal range: make_coef admits
+// 2^-100 < d < 2^100 only, and an x outside 2^-800 <= |x| < 2^800 (zeros, whose sign the FMA
+// chain would lose, infinities and NaN included) takes the division instruction; the range test
+// is one unsigned compare on the exponent bits.  Explicit fma() calls are not contractions:
+// -ffp-contract=off does not affect them.
 __device__ __forceinline__ double div_d(double x, const Coef &c)
 {
-    if (!c.fma_div) return x / c.d;
+    constexpr uint32_t kLo = (1023u - 800u) << 20, kSpan = 1600u << 20;
+    const uint32_t mag = (uint32_t)__double2hiint(x) & 0x7fffffffu;
+    if (!c.fma_div || mag - kLo >= kSpan) return x / c.d;
     const double q0 = x * c.rd;
     const double q1 = fma(fma(-q0, c.d, x), c.rd, q0);
     return fma(fma(-q1, c.d, x), c.rd, q1);
@@ -105,6 +111,10 @@ __device__ __forceinline__ double block_sum(double v, double *lds)
 
 // v = v / EPS_0 in place over the whole view: turns an uploaded rho into the rhs b.
 void div_eps0(hipStream_t s, View v);
+
+// v = dense (rows of d[2] doubles, device memory), divided by EPS_0 when div; dense = v.
+void repitch_in(hipStream_t s, View v, const double *dense, bool div);
+void repitch_out(hipStream_t s, double *dense, View v);
 
 // One colour of red-black GS-SOR on u, updating planes of r within 1..n-2 (n = level size).
 void smooth_colour(hipStream_t s, View u, View rhs, const int64_t n[3], Coef c, double omega,

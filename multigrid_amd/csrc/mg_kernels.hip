@@ -29,6 +29,27 @@ __global__ __launch_bounds__(256) void k_div_eps0(View v)
     p[0] = p[0] / kEps0;
 }
 
+// Dense rows of nk doubles (the caller's array, already in device memory) -> rows of the
+// view's pitch, optionally divided by EPS_0 on the way; and back.
+__global__ __launch_bounds__(256) void k_repitch_in(View v, const double *__restrict__ dense, int div)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBX + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.y * kBY + threadIdx.y;
+    const int64_t i = blockIdx.z;
+    if (k >= v.d[2] || j >= v.d[1]) return;
+    const double x = dense[(i * v.d[1] + j) * v.d[2] + k];
+    v.p[i * v.si + j * v.sj + k] = div ? x / kEps0 : x;
+}
+
+__global__ __launch_bounds__(256) void k_repitch_out(double *__restrict__ dense, View v)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBX + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.y * kBY + threadIdx.y;
+    const int64_t i = blockIdx.z;
+    if (k >= v.d[2] || j >= v.d[1]) return;
+    dense[(i * v.d[1] + j) * v.d[2] + k] = v.p[i * v.si + j * v.sj + k];
+}
+
 // One colour of GS-SOR.  u_new = u + omega*(g - u),
 // g = (((b + cx*(u[i-1]+u[i+1])) + cy*(u[j-1]+u[j+1])) + cz*(u[k-1]+u[k+1])) / d
 // (reference cpp/PotentialSolver.cpp:3780-3786 and :3929-3935).
@@ -271,14 +292,14 @@ Coef make_coef(double cx, double cy, double cz, double d)
     c.cz = cz;
     c.d = d;
     c.rd = 1.0 / d;
-    // the reciprocal form needs a normal, finite d whose significand is not all ones, and a
-    // quotient range far from overflow/underflow (always true for mesh coefficients)
+    // the reciprocal form needs a positive d within 2^-100..2^100 (any real mesh coefficient)
+    // whose significand is not all ones; div_d() bounds the numerator
     uint64_t bits;
     memcpy(&bits, &d, sizeof(bits));
     const uint64_t frac = bits & 0xFFFFFFFFFFFFFull;
     const int expo = (int)((bits >> 52) & 0x7FF);
     static const bool exact_div = getenv("MG_EXACT_DIV") != nullptr;  // A/B: force true division
-    c.fma_div = (!exact_div && d > 0 && expo > 100 && expo < 1900 && frac != 0xFFFFFFFFFFFFFull) ? 1 : 0;
+    c.fma_div = (!exact_div && d > 0 && expo > 923 && expo < 1123 && frac != 0xFFFFFFFFFFFFFull) ? 1 : 0;
     return c;
 }
 
@@ -304,6 +325,16 @@ static int sumsq_blocks(int64_t count)
 }
 
 int64_t sumsq_partials(int64_t count) { return sumsq_blocks(count); }
+
+void repitch_in(hipStream_t s, View v, const double *dense, bool div)
+{
+    hipLaunchKernelGGL(k_repitch_in, grid_for(v.d[2], v.d[1], v.d[0]), dim3(kBX, kBY), 0, s, v, dense, div ? 1 : 0);
+}
+
+void repitch_out(hipStream_t s, double *dense, View v)
+{
+    hipLaunchKernelGGL(k_repitch_out, grid_for(v.d[2], v.d[1], v.d[0]), dim3(kBX, kBY), 0, s, dense, v);
+}
 
 void div_eps0(hipStream_t s, View v)
 {

@@ -21,6 +21,35 @@ def test_compute_ef_operator(gpu, orc, shape):
     assert_bit_equal(gpu.op_compute_ef(phi, dh), orc.compute_ef(phi, dh), "ef")
 
 
+@pytest.mark.parametrize("scale", [0.0, 1e-320, 1e-300, 1e-250, 1e250, 1e305], ids=str)
+def test_compute_ef_extreme_magnitudes(gpu, orc, scale):
+    """Zeros keep their sign (-(0 - 0)/(2h) = -0), subnormal and near-overflow quotients round like
+    the division instruction: the range where the reciprocal-FMA form is not used."""
+    shape = (9, 20, 70)
+    phi = phi_like(shape, rng(22)) * 1e-3 * scale
+    phi[2:5, 3:9, 10:40] = 0.0
+    dh = (0.01, 0.02, 0.03)
+    with np.errstate(over="ignore", invalid="ignore"):
+        want = orc.compute_ef(phi, dh)
+    assert_bit_equal(gpu.op_compute_ef(phi, dh), want, "ef")
+
+
+def test_smoother_extreme_magnitudes(gpu, orc):
+    """The same for the division in the smoother update."""
+    shape = (12, 40, 70)
+    n = shape
+    c = orc.coeffs((0.01, 0.02, 0.03), 0)
+    for scale in (0.0, 1e-318, 1e-290, 1e290):
+        g = rng(23)
+        u, rhs = phi_like(shape, g) * 1e-3 * scale, phi_like(shape, g) * 1e-3 * scale * c[3]
+        u[3:6, 5:20, 8:30] = 0.0
+        rhs[3:6, 5:20, 8:30] = 0.0
+        with np.errstate(over="ignore", invalid="ignore"):
+            want = orc.smooth(u.copy(), rhs, n, c, 1.4, 2, rb=True)
+        got = gpu.op_smooth_rb(u.copy(), rhs, n, c, 1.4, 2)
+        assert_bit_equal(got, want, f"smoother at scale {scale}")
+
+
 def test_compute_ef_on_the_handle_follows_the_solve(gpu, orc):
     """mg_compute_ef works on the device-resident phi a solve left behind."""
     N = (41, 41, 41)
