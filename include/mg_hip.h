@@ -269,6 +269,17 @@ int mg_dev_restrict27(void *stream, const mg_dev_array *Rf, const mg_dev_array *
 int mg_dev_prolong(void *stream, const mg_dev_array *ec, const mg_dev_array *out,
                    const int64_t n[3], int64_t lo, int64_t hi, int correct);
 
+/* mg_dev_smooth_rb preceded by the prolongation from ec (the next coarser level's eps):
+ * correct != 0: u := u - P(ec) (u = phi, cpp/PotentialSolver.cpp:4170-4214), else u := P(ec)
+ * over 0..n-2 (cpp/PotentialSolver.cpp:3940-3976).  The operation is applied to planes
+ * [lo-2, hi+2) of u as far as they are stored -- folded into the first sweep's loads where
+ * the single-pass kernel runs (halo planes of u are then left as they were: the caller
+ * exchanges halos after a sweep anyway), as separate launches otherwise.  ec must hold the
+ * coarse planes those fine planes interpolate from.  sweeps >= 1. */
+int mg_dev_prolong_smooth_rb(void *stream, const mg_dev_array *ec, int correct, const mg_dev_array *u,
+                             const mg_dev_array *alt, const mg_dev_array *rhs, const int64_t n[3],
+                             const double c[4], double omega, int sweeps, int64_t lo, int64_t hi,
+                             int *result_in_alt);
 /* Planes [lo,hi) of E = -grad(phi) (cpp/PotentialSolver.cpp:418-458).  ef is a dense device
  * array [plane][nj][nk][3] whose plane 0 is global plane ef_i0 (no row padding).  Reads phi
  * planes [lo-1, hi+1), plus plane 2 when lo == 0 and plane n-3 when hi == n. */

@@ -1071,6 +1071,41 @@ int mg_dev_prolong(void *stream, const mg_dev_array *ec, const mg_dev_array *out
     return MG_OK;
 }
 
+int mg_dev_prolong_smooth_rb(void *stream, const mg_dev_array *ec, int correct, const mg_dev_array *u,
+                             const mg_dev_array *alt, const mg_dev_array *rhs, const int64_t n[3],
+                             const double c[4], double omega, int sweeps, int64_t lo, int64_t hi,
+                             int *result_in_alt)
+{
+    if (!n || !c || !result_in_alt || sweeps < 1) return fail(MG_ERR_INVALID, "bad argument");
+    View vc, vu, va, vr;
+    TRY(dev_view(ec, &vc, "mg_dev_prolong_smooth_rb(ec)"));
+    TRY(dev_view(u, &vu, "mg_dev_prolong_smooth_rb(u)"));
+    TRY(dev_view(alt, &va, "mg_dev_prolong_smooth_rb(alt)"));
+    TRY(dev_view(rhs, &vr, "mg_dev_prolong_smooth_rb(rhs)"));
+    if (va.d[0] != vu.d[0] || va.d[1] != vu.d[1] || va.d[2] != vu.d[2] || va.i0 != vu.i0)
+        return fail(MG_ERR_INVALID, "mg_dev_prolong_smooth_rb: alt must have the shape of u");
+    if (lo < vu.i0 || hi > vu.i_end() || lo > hi) return fail(MG_ERR_INVALID, "mg_dev_prolong_smooth_rb: bad plane range");
+    if (vc.d[1] < (n[1] >> 1) + 1 || vc.d[2] < (n[2] >> 1) + 1)
+        return fail(MG_ERR_INVALID, "mg_dev_prolong_smooth_rb: coarse array smaller than (n>>1)+1");
+    const int64_t ulo = lo < 1 ? 1 : lo, uhi = hi > n[0] - 1 ? n[0] - 1 : hi;
+    if (ulo < uhi) {
+        TRY(need_planes(vu, ulo - 2, uhi + 2, n[0], "mg_dev_prolong_smooth_rb(u)"));
+        TRY(need_planes(vr, ulo - 1, uhi + 1, n[0] - 1, "mg_dev_prolong_smooth_rb(rhs)"));
+    }
+    {
+        // fine planes the operation is applied to, and the coarse planes they interpolate from
+        int64_t flo = lo - 2 < vu.i0 ? vu.i0 : lo - 2, fhi = hi + 2 > vu.i_end() ? vu.i_end() : hi + 2;
+        if (fhi > n[0] - 1) fhi = n[0] - 1;
+        if (flo < fhi) TRY(need_planes(vc, flo >> 1, ((fhi - 1) >> 1) + 2, (n[0] >> 1) + 1, "mg_dev_prolong_smooth_rb(ec)"));
+    }
+    const double *before = vu.p;
+    mgk::prolong_smooth_rb((hipStream_t)stream, vc, correct != 0, &vu, &va, vr, n, coef4(c), omega, sweeps,
+                           IRange{lo, hi});
+    HIP_TRY(hipGetLastError());
+    *result_in_alt = vu.p != before;
+    return MG_OK;
+}
+
 int mg_dev_compute_ef(void *stream, const mg_dev_array *phi, void *ef, int64_t ef_i0, const int64_t n[3],
                       const double dh[3], int64_t lo, int64_t hi)
 {

@@ -423,18 +423,23 @@ int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, 
                       const int64_t n[3], Coef c, double omega, int sweeps, IRange r)
 {
     static const bool allow = getenv("MG_NO_ONLOAD") == nullptr;  // A/B: force separate launches
-    const bool whole = u->i0 == 0 && r.lo == 0 && r.hi == u->d[0];
     // On-load prolongation pays on big levels only (measured at 129^3: 35 us fused against
     // 23 + 5 us separate; at 257^3: 125 against 107 + 27); the fine-grid correction always pays.
     const bool big = correct || (u->d[1] >= 256 && u->d[2] >= 256);
-    if (allow && whole && big && sweeps > 0 && alt && alt->p && use_fused_sweep(*u)) {
+    if (allow && big && sweeps > 0 && alt && alt->p && use_fused_sweep(*u)) {
         sweep_rb_fused_onload(s, *u, *alt, rhs, ec, correct, n, c, omega, r);
         View t = *u;
         *u = *alt;
         *alt = t;
         return 1 + smooth_rb(s, u, alt, rhs, n, c, omega, sweeps - 1, r);
     }
-    IRange pr{r.lo, r.hi > n[0] ? n[0] : r.hi};
+    // separate launches: the operation must reach every stored plane the first sweep reads
+    // (planes r.lo-2 .. r.hi+1; in a slab those are halo planes, whose coarse neighbours the
+    // caller keeps current)
+    IRange pr{r.lo - 2, r.hi + 2};
+    if (pr.lo < u->i0) pr.lo = u->i0;
+    if (pr.hi > u->i_end()) pr.hi = u->i_end();
+    if (pr.hi > n[0]) pr.hi = n[0];
     if (correct) prolong_correct(s, ec, *u, n, pr);
     else prolong(s, ec, *u, n, pr);
     return 1 + smooth_rb(s, u, alt, rhs, n, c, omega, sweeps, r);

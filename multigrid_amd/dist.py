@@ -154,6 +154,15 @@ class HipOps:
                                               omega, sweeps, lo, hi, C.byref(flag)))
         return bool(flag.value)
 
+    def prolong_smooth(self, ec, correct, u, alt, rhs, n, c, omega, lo, hi):
+        """One sweep preceded by u := P(ec) (or u -= P(ec) when correct) on the stored planes the
+        sweep reads.  Returns True when the result landed in `alt`."""
+        flag = C.c_int(0)
+        self._check(self.lib.mg_dev_prolong_smooth_rb(
+            self._stream(), C.byref(self._arr(ec)), int(correct), C.byref(self._arr(u)), C.byref(self._arr(alt)),
+            C.byref(self._arr(rhs)), (C.c_int64 * 3)(*n), (C.c_double * 4)(*c), omega, 1, lo, hi, C.byref(flag)))
+        return bool(flag.value)
+
     def residual_restrict(self, phi, b, Rc, n, c, lo, hi):
         """Returns a 1-element tensor holding this rank's sum of squared residuals."""
         count = C.c_int64(0)
@@ -316,6 +325,7 @@ class DistSolver:
                 self.cR[l], self.ceps[l], self.ceps_alt[l] = whole(l, "R"), whole(l, "eps"), whole(l, "eps")
         self.n_nodes = float(self.plan.n0[0]) * self.plan.n0[1] * self.plan.n0[2]
         self.last_sum = None
+        self.correction_pending = False
 
     # -- data in / out
     def own(self, l, kind):
@@ -330,21 +340,30 @@ class DistSolver:
     def set_phi(self, phi_of_planes):
         lo, hi = self.plan.stored(0, "phi", self.rank, self.H_U)
         self.ops.upload(self.phi, phi_of_planes(lo, hi), lo)
+        self.correction_pending = False
 
     def get_phi_owned(self):
+        self.flush_correction()
         lo, hi = self.own(0, "phi")
         return lo, self.phi.data(lo, hi)
 
     # -- the cycle
-    def _sweeps(self, l):
-        """nu[l] red-black sweeps of a distributed level, one halo exchange after each."""
+    def _sweeps(self, l, ec=None, correct=False):
+        """nu[l] red-black sweeps of a distributed level, one halo exchange after each.  With `ec`
+        (eps of level l+1, halos current) the first sweep is preceded by the prolongation from it:
+        u := P(ec), or u -= P(ec) when `correct` -- folded into that sweep's loads where possible."""
         n = self.plan.level_n(l)
-        for _ in range(self.nu[l]):
+        for sweep in range(self.nu[l]):
             if l == 0:
                 u, alt, rhs, own = self.phi, self.phi_alt, self.b, self.own(0, "phi")
             else:
                 u, alt, rhs, own = self.eps[l], self.eps_alt[l], self.R[l], self.own(l, "eps")
-            if self.ops.smooth(u, alt, rhs, n, self.coef[l], self.omega, 1, own[0], own[1]):
+            if sweep == 0 and ec is not None:
+                swapped = self.ops.prolong_smooth(ec, correct, u, alt, rhs, n, self.coef[l], self.omega,
+                                                  own[0], own[1])
+            else:
+                swapped = self.ops.smooth(u, alt, rhs, n, self.coef[l], self.omega, 1, own[0], own[1])
+            if swapped:
                 if l == 0:
                     self.phi, self.phi_alt = alt, u
                 else:
@@ -352,18 +371,32 @@ class DistSolver:
                 u = alt
             self.comm.exchange(u, own, self.H_U)
 
+    def flush_correction(self):
+        """Apply a coarse-grid correction that is still waiting for the next fine sweep."""
+        if self.correction_pending:
+            # phi -= P(eps_1) on every stored plane, halos included: eps_1's halos are current
+            lo, hi = self.plan.stored(0, "phi", self.rank, self.H_U)
+            self.ops.prolong(self.eps[1], self.phi, self.plan.n0, lo, hi, True)
+            self.correction_pending = False
+
     def smooth_and_residual(self):
         """Steps 1)-2b) of the reference iteration (+ the restriction to level 1, which shares the
         pass).  Returns the global sum of squared residuals as a 1-element tensor."""
-        self._sweeps(0)
+        if self.correction_pending and self.nu[0] > 0:
+            self._sweeps(0, self.eps[1], True)   # step 6) of the previous iteration rides along
+            self.correction_pending = False
+        else:
+            self.flush_correction()
+            self._sweeps(0)
         lo, hi = self.own(0, "phi")
         s = self.ops.residual_restrict(self.phi, self.b, self.R[1], self.plan.n0, self.coef[0], lo, hi)
         self.last_sum = self.comm.allreduce_sum(s)
         return self.last_sum
 
     def coarse_correction(self):
-        """Steps 3)-6): restrict down to the cut level, gather, solve the small levels on rank 0,
-        scatter, then (prolong, smooth) up and correct phi."""
+        """Steps 3)-5): restrict down to the cut level, gather, solve the small levels on rank 0,
+        scatter, then (prolong, smooth) up.  Step 6), the correction of phi, is left pending for the
+        next iteration's first sweep (flush_correction() applies it when no iteration follows)."""
         P, ops, comm = self.plan, self.ops, self.comm
         for l in range(1, self.cut):
             # R_l's halo plane below feeds the restriction; both feed the sweeps' red halo planes
@@ -375,13 +408,15 @@ class DistSolver:
             self._coarse_levels()
         comm.scatter_planes(P, self.cut, "eps", self.ceps.get(self.cut), self.eps[self.cut], self.H_U)
         for l in range(self.cut - 1, 0, -1):
-            lo, hi = self.own(l, "eps")
-            ops.prolong(self.eps[l + 1], self.eps[l], P.level_n(l), lo, hi, False)
-            comm.exchange(self.eps[l], (lo, hi), self.H_U)
-            self._sweeps(l)
-        # phi -= P(eps_1) on every stored plane, halos included: eps_1's halos are current
-        lo, hi = P.stored(0, "phi", self.rank, self.H_U)
-        ops.prolong(self.eps[1], self.phi, P.n0, lo, hi, True)
+            if self.nu[l] > 0:
+                # eps_l = P(eps_{l+1}) as the first sweep's input, on halo planes too (eps_{l+1}'s
+                # halos are current), so the prolongation needs no exchange of its own
+                self._sweeps(l, self.eps[l + 1], False)
+            else:
+                lo, hi = P.stored(l, "eps", self.rank, self.H_U)
+                ops.prolong(self.eps[l + 1], self.eps[l], P.level_n(l), lo, hi, False)
+        # step 6), phi -= P(eps_1), waits for the next iteration's first fine sweep
+        self.correction_pending = True
 
     def _coarse_levels(self):
         """Levels cut..depth on whole arrays (rank 0): restrict down, smooth the coarsest,
@@ -405,6 +440,7 @@ class DistSolver:
         for _ in range(count):
             s = self.smooth_and_residual()
             self.coarse_correction()
+        self.flush_correction()
         self.ops.sync()
         return self.l2(s)
 
@@ -417,4 +453,5 @@ class DistSolver:
             if l2 < tol:
                 return True, it + 1, l2
             self.coarse_correction()
+        self.flush_correction()
         return False, max_it, l2

@@ -34,6 +34,11 @@ class OracleOps:
                                          (C.c_double * 4)(*c), omega, lo, hi)
         return False  # in place
 
+    def prolong_smooth(self, ec, correct, u, alt, rhs, n, c, omega, lo, hi):
+        plo, phi_ = max(lo - 2, u.i0), min(hi + 2, u.i0 + u.planes, n[0])
+        self.prolong(ec, u, n, plo, phi_, correct)
+        return self.smooth(u, alt, rhs, n, c, omega, 1, lo, hi)
+
     def residual_restrict(self, phi, b, Rc, n, c, lo, hi):
         s = orc.lib().orc_slab_residual_restrict(C.byref(self._v(phi)), C.byref(self._v(b)), C.byref(self._v(Rc)),
                                                  (C.c_int64 * 3)(*n), (C.c_double * 4)(*c), lo, hi)

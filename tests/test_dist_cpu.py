@@ -31,7 +31,11 @@ def _worker(rank, world, port, n, depth, cut, cycles, out_dir):
         s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, OracleOps(), mgd.Comm(), cut=cut)
         s.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
         s.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
-        hist = [s.vcycles(1) for _ in range(cycles)]
+        hist = []
+        for _ in range(cycles):  # the correction of one iteration rides on the next one's first sweep
+            s.smooth_and_residual()
+            hist.append(s.l2())
+            s.coarse_correction()
         lo, phi = s.get_phi_owned()
         np.save(os.path.join(out_dir, f"phi_{rank}.npy"), phi)
         np.save(os.path.join(out_dir, f"lo_{rank}.npy"), np.array([lo]))
