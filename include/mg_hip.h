@@ -243,6 +243,11 @@ int64_t mg_dev_pitch(int64_t nk);
 int mg_level_coef(const double dh[3], int level, double out[4]);
 /* v /= EPS_0 over the whole array. */
 int mg_dev_div_eps0(void *stream, const mg_dev_array *v);
+/* 1 when mg_dev_smooth_rb on an array of this shape runs the out-of-place single-pass kernel
+ * (result in alt): one sweep may then be issued as several disjoint plane ranges, e.g. the
+ * planes next to a neighbour first so that their halo exchange overlaps the rest.  The ptr
+ * member is not read. */
+int mg_dev_sweep_out_of_place(const mg_dev_array *u);
 /* `sweeps` red-black sweeps of planes [lo,hi) of u (right-hand side rhs, level size n).
  * The sweep may be out of place: alt has u's shape; *result_in_alt = 1 when the result
  * landed in alt (the caller swaps its references).  Out-of-place sweeps read planes

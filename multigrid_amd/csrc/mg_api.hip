@@ -976,6 +976,13 @@ int mg_dev_div_eps0(void *stream, const mg_dev_array *v)
     return MG_OK;
 }
 
+int mg_dev_sweep_out_of_place(const mg_dev_array *u)
+{
+    View vu;
+    if (dev_view(u, &vu, "mg_dev_sweep_out_of_place", true)) return 0;
+    return mgk::sweep_is_out_of_place(vu) ? 1 : 0;
+}
+
 int mg_dev_smooth_rb(void *stream, const mg_dev_array *u, const mg_dev_array *alt, const mg_dev_array *rhs,
                      const int64_t n[3], const double c[4], double omega, int sweeps, int64_t lo, int64_t hi,
                      int *result_in_alt)

@@ -129,6 +129,9 @@ void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t 
 // 0..n-2 (a coarse level's prolongated initial guess).  ec = eps of the next coarser level.
 void sweep_rb_fused_onload(hipStream_t s, View uin, View uout, View rhs, View ec, bool correct,
                            const int64_t n[3], Coef c, double omega, IRange r);
+// True when smooth_rb on an array of this shape (with a twin to write to) runs the out-of-place
+// single-pass kernel: disjoint plane ranges of one sweep are then independent launches.
+bool sweep_is_out_of_place(const View &u);
 // `sweeps` red-black sweeps preceded by the prolongation from ec (correct: by phi -= P(ec)):
 // fused into the first sweep where the single-pass kernel is used, separate launches otherwise.
 int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, View rhs,

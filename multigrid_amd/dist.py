@@ -12,6 +12,10 @@ bit-identical to the undivided red-black cycle:
     sides).  A red-black sweep recomputes the red update of the first halo plane on
     either side, so ONE exchange of two planes per side per sweep replaces an exchange
     after every colour;
+  * where the sweep kernel is out of place, a sweep is issued as three plane ranges: the two
+    planes next to each neighbour first, then the exchange of exactly those planes is started,
+    then the interior -- which needs no halo plane of the previous sweep either -- so the
+    exchange runs under the interior sweep; the fine residual is split the same way;
   * the sum of squared residuals is all-reduced once per cycle;
   * level `cut` and everything below it is gathered onto rank 0, solved there on
     whole arrays, and eps_cut is scattered back.
@@ -87,6 +91,13 @@ class Slab:
         self.i0, self.nj, self.nk = int(i0), int(nj), int(nk)
         self.pitch = (self.nk + 1) & ~1
         self.t = ops.zeros((int(planes), self.nj, self.pitch))
+        self.pending = None  # halo exchange in flight into this slab (Comm.exchange_start)
+
+    def ready(self):
+        """Block the compute stream until the halo planes in flight have arrived."""
+        if self.pending is not None:
+            self.pending()
+            self.pending = None
 
     @property
     def planes(self):
@@ -143,6 +154,10 @@ class HipOps:
         return tuple(out)
 
     # -- operators
+    def out_of_place(self, u):
+        """True when a sweep of this slab reads u and writes alt (so plane ranges are independent)."""
+        return bool(self.lib.mg_dev_sweep_out_of_place(C.byref(self._arr(u))))
+
     def div_eps0(self, v):
         self._check(self.lib.mg_dev_div_eps0(self._stream(), C.byref(self._arr(v))))
 
@@ -155,23 +170,30 @@ class HipOps:
         return bool(flag.value)
 
     def prolong_smooth(self, ec, correct, u, alt, rhs, n, c, omega, lo, hi):
-        """One sweep preceded by u := P(ec) (or u -= P(ec) when correct) on the stored planes the
-        sweep reads.  Returns True when the result landed in `alt`."""
+        """One sweep of planes [lo,hi) preceded by u := P(ec) (or u -= P(ec) when correct) on the
+        stored planes the sweep reads.  Returns True when the result landed in `alt`."""
         flag = C.c_int(0)
         self._check(self.lib.mg_dev_prolong_smooth_rb(
             self._stream(), C.byref(self._arr(ec)), int(correct), C.byref(self._arr(u)), C.byref(self._arr(alt)),
             C.byref(self._arr(rhs)), (C.c_int64 * 3)(*n), (C.c_double * 4)(*c), omega, 1, lo, hi, C.byref(flag)))
         return bool(flag.value)
 
-    def residual_restrict(self, phi, b, Rc, n, c, lo, hi):
-        """Returns a 1-element tensor holding this rank's sum of squared residuals."""
-        count = C.c_int64(0)
-        self._check(self.lib.mg_dev_residual_restrict(
-            self._stream(), C.byref(self._arr(phi)), C.byref(self._arr(b)), C.byref(self._arr(Rc)),
-            (C.c_int64 * 3)(*n), (C.c_double * 4)(*c), C.c_void_p(self.partials.data_ptr()),
-            self.partials.numel(), lo, hi, C.byref(count)))
+    def residual_restrict(self, phi, b, Rc, n, c, parts, before_part=None):
+        """Fused residual + restriction over the plane ranges `parts` (each even-aligned), one launch
+        per range; before_part(i) runs ahead of launch i.  Returns a 1-element tensor holding this
+        rank's sum of squared residuals."""
+        used = 0
+        for idx, (lo, hi) in enumerate(parts):
+            if before_part:
+                before_part(idx)
+            count = C.c_int64(0)
+            self._check(self.lib.mg_dev_residual_restrict(
+                self._stream(), C.byref(self._arr(phi)), C.byref(self._arr(b)), C.byref(self._arr(Rc)),
+                (C.c_int64 * 3)(*n), (C.c_double * 4)(*c), C.c_void_p(self.partials.data_ptr() + 8 * used),
+                self.partials.numel() - used, lo, hi, C.byref(count)))
+            used += count.value
         self._check(self.lib.mg_dev_sum_partials(self._stream(), C.c_void_p(self.partials.data_ptr()),
-                                                 count.value, C.c_void_p(self.scalar.data_ptr())))
+                                                 used, C.c_void_p(self.scalar.data_ptr())))
         return self.scalar
 
     def restrict27(self, Rf, Rc, nf, lo, hi):
@@ -191,8 +213,12 @@ class HipOps:
 class Comm:
     """Halo exchange, all-reduce and gather/scatter over torch.distributed point-to-point ops."""
 
-    def __init__(self, group=None, stage_through_host=None):
+    def __init__(self, group=None, stage_through_host=None, defer=False):
         self.group = group
+        # defer: run a started exchange only when its slab is next needed (slab.ready()).  RCCL moves
+        # the planes some time between start and completion; the blocking path is the earliest case,
+        # this is the latest one -- the tests run both to pin the schedule's dependencies.
+        self.defer = defer
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bytes_sent = 0
@@ -219,23 +245,49 @@ class Comm:
         for dst, h in back:
             dst.copy_(h)
 
-    def exchange(self, slab, own, width):
-        """Fill this rank's halo planes of `slab` (up to `width` per side) from the neighbours'
-        owned planes and send ours: planes are contiguous, one message per neighbour per direction."""
-        if self.world == 1:
-            return
+    def _halo_ops(self, slab, own, width):
         lo, hi = own
         ops = []
         if self.rank + 1 < self.world:
-            w_up = min(width, slab.i0 + slab.planes - hi)  # halo planes stored above
+            assert slab.i0 + slab.planes - hi >= width  # halo planes stored above
             ops.append(dist.P2POp(dist.isend, slab.rows(hi - width, hi), self.rank + 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, slab.rows(hi, hi + w_up), self.rank + 1, self.group))
-            assert w_up == width
+            ops.append(dist.P2POp(dist.irecv, slab.rows(hi, hi + width), self.rank + 1, self.group))
         if self.rank > 0:
             ops.append(dist.P2POp(dist.isend, slab.rows(lo, lo + width), self.rank - 1, self.group))
             ops.append(dist.P2POp(dist.irecv, slab.rows(lo - width, lo), self.rank - 1, self.group))
         self.bytes_sent += sum(o.tensor.numel() * 8 for o in ops if o.op is dist.isend)
-        self._run(ops)
+        return ops
+
+    def exchange(self, slab, own, width):
+        """Fill this rank's halo planes of `slab` (`width` per side) from the neighbours' owned
+        planes and send ours: planes are contiguous, one message per neighbour per direction."""
+        if self.world == 1:
+            return
+        slab.ready()
+        self._run(self._halo_ops(slab, own, width))
+
+    def exchange_start(self, slab, own, width):
+        """The same exchange, started now and completed by slab.ready().  With RCCL the transfers
+        are ordered after the kernels enqueued so far and run beside the ones enqueued next; the
+        host-staged path (gloo) completes here."""
+        if self.world == 1:
+            return
+        slab.ready()
+        ops = self._halo_ops(slab, own, width)
+        if not ops:
+            return
+        if self.defer:
+            slab.pending = lambda: self._run(ops)
+            return
+        if self.stage and any(o.tensor.is_cuda for o in ops) or not ops[0].tensor.is_cuda:
+            self._run(ops)
+            return
+        works = dist.batch_isend_irecv(ops)
+
+        def finish():
+            for w in works:
+                w.wait()
+        slab.pending = finish
 
     def allreduce_sum(self, t):
         if self.world > 1:
@@ -292,8 +344,9 @@ class DistSolver:
 
     H_U, H_RHS = 2, 1  # halo planes of swept fields / of right-hand sides
 
-    def __init__(self, n0, dh, depth, ops, comm, nu=None, omega=1.4, cut=None, cut_size=128):
+    def __init__(self, n0, dh, depth, ops, comm, nu=None, omega=1.4, cut=None, cut_size=128, overlap=True):
         self.ops, self.comm = ops, comm
+        self.overlap = overlap  # run halo exchanges under the interior part of the sweeps
         self.rank, self.world = comm.rank, comm.world
         self.plan = SlabPlan(n0, depth, self.world, cut, cut_size)
         self.depth, self.cut = depth, self.plan.cut
@@ -344,38 +397,68 @@ class DistSolver:
 
     def get_phi_owned(self):
         self.flush_correction()
+        self.phi.ready()
         lo, hi = self.own(0, "phi")
         return lo, self.phi.data(lo, hi)
 
     # -- the cycle
+    def _split(self, own, first, last):
+        """Plane ranges of an owned slab: the two planes next to each existing neighbour (what a
+        halo exchange of width 2 sends) and the interior between them."""
+        lo, hi = own
+        a = lo + self.H_U if not first else lo
+        b = hi - self.H_U if not last else hi
+        return ([(lo, a)] if a > lo else []) + ([(b, hi)] if b < hi else []), (a, b)
+
     def _sweeps(self, l, ec=None, correct=False):
         """nu[l] red-black sweeps of a distributed level, one halo exchange after each.  With `ec`
         (eps of level l+1, halos current) the first sweep is preceded by the prolongation from it:
         u := P(ec), or u -= P(ec) when `correct` -- folded into that sweep's loads where possible."""
         n = self.plan.level_n(l)
+        first, last = self.rank == 0, self.rank == self.world - 1
         for sweep in range(self.nu[l]):
             if l == 0:
                 u, alt, rhs, own = self.phi, self.phi_alt, self.b, self.own(0, "phi")
             else:
                 u, alt, rhs, own = self.eps[l], self.eps_alt[l], self.R[l], self.own(l, "eps")
+
+            def run(lo, hi):
+                if sweep == 0 and ec is not None:
+                    return self.ops.prolong_smooth(ec, correct, u, alt, rhs, n, self.coef[l], self.omega, lo, hi)
+                return self.ops.smooth(u, alt, rhs, n, self.coef[l], self.omega, 1, lo, hi)
+
             if sweep == 0 and ec is not None:
-                swapped = self.ops.prolong_smooth(ec, correct, u, alt, rhs, n, self.coef[l], self.omega,
-                                                  own[0], own[1])
+                ec.ready()
+            edges, inner = self._split(own, first, last)
+            overlap = (self.world > 1 and self.overlap and self.ops.out_of_place(u)
+                       and inner[1] - inner[0] >= 2 * self.H_U)
+            if overlap:
+                # edge planes need the halos of the previous sweep; the interior does not
+                u.ready()
+                swapped = [run(lo, hi) for lo, hi in edges]
+                self.comm.exchange_start(alt, own, self.H_U)
+                swapped.append(run(*inner))
+                assert all(swapped), "out-of-place sweep expected"
+                swapped = True
             else:
-                swapped = self.ops.smooth(u, alt, rhs, n, self.coef[l], self.omega, 1, own[0], own[1])
+                u.ready()
+                swapped = run(*own)
             if swapped:
                 if l == 0:
                     self.phi, self.phi_alt = alt, u
                 else:
                     self.eps[l], self.eps_alt[l] = alt, u
                 u = alt
-            self.comm.exchange(u, own, self.H_U)
+            if not overlap:
+                self.comm.exchange(u, own, self.H_U)
 
     def flush_correction(self):
         """Apply a coarse-grid correction that is still waiting for the next fine sweep."""
         if self.correction_pending:
             # phi -= P(eps_1) on every stored plane, halos included: eps_1's halos are current
             lo, hi = self.plan.stored(0, "phi", self.rank, self.H_U)
+            self.eps[1].ready()
+            self.phi.ready()
             self.ops.prolong(self.eps[1], self.phi, self.plan.n0, lo, hi, True)
             self.correction_pending = False
 
@@ -388,8 +471,19 @@ class DistSolver:
         else:
             self.flush_correction()
             self._sweeps(0)
-        lo, hi = self.own(0, "phi")
-        s = self.ops.residual_restrict(self.phi, self.b, self.R[1], self.plan.n0, self.coef[0], lo, hi)
+        own = self.own(0, "phi")
+        edges, inner = self._split(own, self.rank == 0, self.rank == self.world - 1)
+        # slab boundaries are multiples of 2^cut, so every range below starts on an even plane
+        if self.world > 1 and self.overlap and inner[1] - inner[0] >= 2 * self.H_U:
+            # the interior needs no halo plane: it runs while the last sweep's exchange completes
+            parts = [inner] + ([(own[0], inner[0])] if inner[0] > own[0] else []) + \
+                    ([(inner[1], own[1])] if inner[1] < own[1] else [])
+            wait_at = 1
+        else:
+            parts, wait_at = [own], 0
+        s = self.ops.residual_restrict(self.phi, self.b, self.R[1], self.plan.n0, self.coef[0], parts,
+                                       lambda idx: self.phi.ready() if idx == wait_at else None)
+        self.phi.ready()
         self.last_sum = self.comm.allreduce_sum(s)
         return self.last_sum
 
@@ -414,6 +508,7 @@ class DistSolver:
                 self._sweeps(l, self.eps[l + 1], False)
             else:
                 lo, hi = P.stored(l, "eps", self.rank, self.H_U)
+                self.eps[l + 1].ready()
                 ops.prolong(self.eps[l + 1], self.eps[l], P.level_n(l), lo, hi, False)
         # step 6), phi -= P(eps_1), waits for the next iteration's first fine sweep
         self.correction_pending = True

@@ -85,6 +85,7 @@ SYMBOLS = {
     "mg_dev_pitch": (C.c_int64, [C.c_int64]),
     "mg_level_coef": (C.c_int, [_f64x3, C.c_int, C.c_double * 4]),
     "mg_dev_div_eps0": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray)]),
+    "mg_dev_sweep_out_of_place": (C.c_int, [C.POINTER(MgDevArray)]),
     "mg_dev_smooth_rb": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.POINTER(MgDevArray), C.POINTER(MgDevArray),
                                    _i64x3, C.c_double * 4, C.c_double, C.c_int, C.c_int64, C.c_int64,
                                    C.POINTER(C.c_int)]),

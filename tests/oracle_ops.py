@@ -12,6 +12,15 @@ from oracle import mg_oracle as orc
 
 
 class OracleOps:
+    """out_of_place=True makes a sweep read u and write alt, like the GPU's single-pass kernel, so
+    that the solver issues sweeps as edge and interior plane ranges around the halo exchange."""
+
+    def __init__(self, out_of_place=False):
+        self._oop = out_of_place
+
+    def out_of_place(self, u):
+        return self._oop
+
     def zeros(self, shape):
         return torch.zeros(shape, dtype=torch.float64)
 
@@ -29,6 +38,17 @@ class OracleOps:
         orc.lib().orc_slab_div_eps0(C.byref(self._v(v)))
 
     def smooth(self, u, alt, rhs, n, c, omega, sweeps, lo, hi):
+        if self._oop and sweeps == 1:
+            # planes [lo,hi) of alt = one sweep of u: run the in-place slab form on a scratch copy of
+            # the planes it touches, keep only the requested planes
+            a, b = max(lo - 2, u.i0), min(hi + 2, u.i0 + u.planes)
+            tmp = type(u).__new__(type(u))
+            tmp.i0, tmp.nj, tmp.nk, tmp.pitch, tmp.pending = a, u.nj, u.nk, u.pitch, None
+            tmp.t = u.rows(a, b).clone()
+            orc.lib().orc_slab_smooth_rb(C.byref(self._v(tmp)), C.byref(self._v(rhs)), (C.c_int64 * 3)(*n),
+                                         (C.c_double * 4)(*c), omega, lo, hi)
+            alt.rows(lo, hi).copy_(tmp.rows(lo, hi))
+            return True
         for _ in range(sweeps):
             orc.lib().orc_slab_smooth_rb(C.byref(self._v(u)), C.byref(self._v(rhs)), (C.c_int64 * 3)(*n),
                                          (C.c_double * 4)(*c), omega, lo, hi)
@@ -36,12 +56,24 @@ class OracleOps:
 
     def prolong_smooth(self, ec, correct, u, alt, rhs, n, c, omega, lo, hi):
         plo, phi_ = max(lo - 2, u.i0), min(hi + 2, u.i0 + u.planes, n[0])
+        if self._oop:
+            # on-load form: u itself stays as it was, the sweep sees the prolongated values
+            src = type(u).__new__(type(u))
+            src.i0, src.nj, src.nk, src.pitch, src.pending = u.i0, u.nj, u.nk, u.pitch, None
+            src.t = u.t.clone()
+            self.prolong(ec, src, n, plo, phi_, correct)
+            return self.smooth(src, alt, rhs, n, c, omega, 1, lo, hi)
         self.prolong(ec, u, n, plo, phi_, correct)
         return self.smooth(u, alt, rhs, n, c, omega, 1, lo, hi)
 
-    def residual_restrict(self, phi, b, Rc, n, c, lo, hi):
-        s = orc.lib().orc_slab_residual_restrict(C.byref(self._v(phi)), C.byref(self._v(b)), C.byref(self._v(Rc)),
-                                                 (C.c_int64 * 3)(*n), (C.c_double * 4)(*c), lo, hi)
+    def residual_restrict(self, phi, b, Rc, n, c, parts, before_part=None):
+        s = 0.0
+        for idx, (lo, hi) in enumerate(parts):
+            if before_part:
+                before_part(idx)
+            s += orc.lib().orc_slab_residual_restrict(C.byref(self._v(phi)), C.byref(self._v(b)),
+                                                      C.byref(self._v(Rc)), (C.c_int64 * 3)(*n),
+                                                      (C.c_double * 4)(*c), lo, hi)
         return torch.tensor([s], dtype=torch.float64)
 
     def restrict27(self, Rf, Rc, nf, lo, hi):

@@ -20,7 +20,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, depth, cut, cycles, out_dir):
+def _worker(rank, world, port, n, depth, cut, cycles, out_dir, oop=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -28,7 +28,7 @@ def _worker(rank, world, port, n, depth, cut, cycles, out_dir):
         from multigrid_amd import dist as mgd, problem
         from oracle_ops import OracleOps
         N = (n, n, n)
-        s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, OracleOps(), mgd.Comm(), cut=cut)
+        s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, OracleOps(bool(oop)), mgd.Comm(defer=oop == 2), cut=cut)
         s.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
         s.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
         hist = []
@@ -42,7 +42,7 @@ def _worker(rank, world, port, n, depth, cut, cycles, out_dir):
         if rank == 0:
             np.save(os.path.join(out_dir, "hist.npy"), np.array(hist))
         # the solve loop: all ranks must agree on the stopping iteration
-        s2 = mgd.DistSolver(N, problem.main_extents_dh(N), depth, OracleOps(), mgd.Comm(), cut=cut)
+        s2 = mgd.DistSolver(N, problem.main_extents_dh(N), depth, OracleOps(bool(oop)), mgd.Comm(defer=oop == 2), cut=cut)
         s2.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
         s2.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
         ok, cyc, l2 = s2.solve(200, 1e-2)
@@ -52,9 +52,15 @@ def _worker(rank, world, port, n, depth, cut, cycles, out_dir):
 
 
 @pytest.mark.parametrize("world,n,depth,cut", [(2, 33, 2, 1), (2, 33, 3, 2), (3, 65, 3, 2), (2, 41, 2, 2)])
-def test_partitioned_cycle_equals_undivided_oracle(orc, tmp_path, world, n, depth, cut):
+@pytest.mark.parametrize("oop", [0, 1, 2], ids=["in_place", "edges_exchange_interior", "exchange_completes_late"])
+def test_partitioned_cycle_equals_undivided_oracle(orc, tmp_path, world, n, depth, cut, oop):
+    """oop: the operators behave like the GPU's out-of-place sweep kernel, which makes the solver
+    issue every sweep (and the fine residual) as edge planes, halo exchange, interior.  With RCCL
+    the exchange completes at some point while the interior runs: the blocking transport is the
+    earliest case, oop == 2 delays every started exchange until its slab is next needed."""
     cycles = 3
-    mp.spawn(_worker, args=(world, free_port(), n, depth, cut, cycles, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, free_port(), n, depth, cut, cycles, str(tmp_path), oop), nprocs=world,
+             join=True)
     N = (n, n, n)
     dh = orc.main_extents_dh(N)
     rho = orc.synthetic_rho(N)

@@ -20,7 +20,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, depth, cut, cycles, out_dir):
+def _worker(rank, world, port, n, depth, cut, cycles, out_dir, defer):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -29,7 +29,7 @@ def _worker(rank, world, port, n, depth, cut, cycles, out_dir):
     try:
         from multigrid_amd import dist as mgd, problem
         N = (n, n, n)
-        s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, mgd.HipOps(0), mgd.Comm(), cut=cut)
+        s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, mgd.HipOps(0), mgd.Comm(defer=defer), cut=cut)
         s.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
         s.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
         hist = []
@@ -48,11 +48,17 @@ def _worker(rank, world, port, n, depth, cut, cycles, out_dir):
 
 @pytest.mark.parametrize("world,n,depth,cut,cycles", [(1, 65, 3, 2, 3), (2, 65, 3, 1, 3), (2, 129, 3, 2, 3),
                                                       (2, 257, 5, 2, 3), (3, 257, 5, 3, 2), (2, 513, 5, 3, 2)])
-def test_partitioned_gpu_cycle_equals_undivided_oracle(gpu, orc, tmp_path, world, n, depth, cut, cycles):
+@pytest.mark.parametrize("defer", [False, True], ids=["exchange_early", "exchange_late"])
+def test_partitioned_gpu_cycle_equals_undivided_oracle(gpu, orc, tmp_path, world, n, depth, cut, cycles, defer):
     """257^3 and up take the single-pass sweep with the correction folded into its loads on slabs;
-    513^3 also the on-load prolongation of level 1."""
+    513^3 also the on-load prolongation of level 1.  The started halo exchanges complete either at
+    once (gloo is blocking) or as late as the schedule allows (defer), the two extremes of what RCCL
+    may do on a multi-GPU node."""
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(world, free_port(), n, depth, cut, cycles, str(tmp_path)), nprocs=world, join=True)
+    if defer and (world == 1 or n >= 513):
+        pytest.skip("covered by the early-exchange case")
+    mp.spawn(_worker, args=(world, free_port(), n, depth, cut, cycles, str(tmp_path), defer), nprocs=world,
+             join=True)
     N = (n, n, n)
     dh = orc.main_extents_dh(N)
     want = np.zeros(N)
