@@ -310,13 +310,11 @@ static int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
-// One full red-black sweep u_in -> u_out: planes r of u_out, updated over 1..n-2 per axis
-// (n = level size); every other element of those planes is copied through unchanged.
-// load_op (kLoad*) is applied to u_in on the fly with the coarse array ec.
-static void launch_sweep(hipStream_t s, View uin, View uout, View rhs, View ec, int load_op,
-                         const int64_t n[3], Coef c, double omega, IRange r)
+template <int WJ, int NT>
+static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec, int load_op,
+                           const int64_t n[3], Coef c, double omega, IRange r)
 {
-    constexpr int WJ = 32, WKP = 32, D = 2, NT = 256;
+    constexpr int WKP = 32, D = 2;
     constexpr int TJ = WJ - 4, TK = 2 * WKP - 4;
     static const int want_chunks = env_int("MG_SWEEP_CHUNKS", 0);  // tuning knob (A/B runs)
     const int64_t planes = r.hi - r.lo;
@@ -324,7 +322,7 @@ static void launch_sweep(hipStream_t s, View uin, View uout, View rhs, View ec, 
     const int tiles_j = (int)((uin.d[1] + TJ - 1) / TJ);
     const int tiles_k = (int)((uin.d[2] + TK - 1) / TK);
     const int tiles = tiles_j * tiles_k;
-    int nchunks = pick_chunks(tiles, planes, 4);
+    int nchunks = pick_chunks(tiles, planes, 4, 1, WJ == 32 ? 512 : 256);
     if (want_chunks > 0) nchunks = want_chunks;
     const int CI = (int)((planes + nchunks - 1) / nchunks);
     const unsigned grid = (unsigned)(nchunks * tiles);
@@ -336,6 +334,17 @@ static void launch_sweep(hipStream_t s, View uin, View uout, View rhs, View ec, 
     else if (load_op == kLoadProlong) LAUNCH(kLoadProlong);
     else LAUNCH(kLoadPlain);
 #undef LAUNCH
+}
+
+// One full red-black sweep u_in -> u_out: planes r of u_out, updated over 1..n-2 per axis
+// (n = level size); every other element of those planes is copied through unchanged.
+// load_op (kLoad*) is applied to u_in on the fly with the coarse array ec.
+static void launch_sweep(hipStream_t s, View uin, View uout, View rhs, View ec, int load_op,
+                         const int64_t n[3], Coef c, double omega, IRange r)
+{
+    static const int wj = env_int("MG_SWEEP_WJ", 32);
+    if (wj == 64) launch_sweep_t<64, 512>(s, uin, uout, rhs, ec, load_op, n, c, omega, r);
+    else launch_sweep_t<32, 256>(s, uin, uout, rhs, ec, load_op, n, c, omega, r);
 }
 
 void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c,
