@@ -39,13 +39,14 @@ const double *pack(Field &f, std::vector<double> &stage)
 
 }  // namespace
 
-MultiGridSolverHIP::MultiGridSolverHIP(World &w, int max_it, double tol, int depth, int device)
+MultiGridSolverHIP::MultiGridSolverHIP(World &w, int max_it, double tol, int depth, int device, bool variant_b)
     : PotentialSolver(w), max_solver_it(max_it), tolerance(tol)
 {
     mg_config cfg;
     double3 dh = world.getDh();
     const double h[3] = {dh[0], dh[1], dh[2]};
-    check(mg_default_config(&cfg, world.ni, world.nj, world.nk, h, depth), "mg_default_config");
+    if (variant_b) check(mg_default_config_b(&cfg, world.ni, world.nj, world.nk, h, depth), "mg_default_config_b");
+    else check(mg_default_config(&cfg, world.ni, world.nj, world.nk, h, depth), "mg_default_config");
     cfg.device = device;
     check(mg_create(&cfg, &handle), "mg_create");
 }

@@ -33,7 +33,9 @@ class MultiGridSolverHIP : public PotentialSolver {
 public:
     // depth = number of coarse grids (1..5 = the reference's MultiGridSolver, V2, .. V5;
     // 0 only through GaussSeidelSolverHIP)
-    MultiGridSolverHIP(World &world, int max_it, double tol, int depth, int device = 0);
+    // variant_b: the reference's "B" classes (cpp/PotentialSolver.h:274-350): 7-point restriction,
+    // and for depth 5 the sweep schedule 1,2,3,4,5,50
+    MultiGridSolverHIP(World &world, int max_it, double tol, int depth, int device = 0, bool variant_b = false);
     ~MultiGridSolverHIP() override;
     MultiGridSolverHIP(const MultiGridSolverHIP &) = delete;
     MultiGridSolverHIP &operator=(const MultiGridSolverHIP &) = delete;
@@ -77,6 +79,11 @@ struct MultiGridSolverV2 : MultiGridSolverHIP { MultiGridSolverV2(World &w, int 
 struct MultiGridSolverV3 : MultiGridSolverHIP { MultiGridSolverV3(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 3) {} };
 struct MultiGridSolverV4 : MultiGridSolverHIP { MultiGridSolverV4(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 4) {} };
 struct MultiGridSolverV5 : MultiGridSolverHIP { MultiGridSolverV5(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 5) {} };
+struct MultiGridSolverB : MultiGridSolverHIP { MultiGridSolverB(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 1, 0, true) {} };
+struct MultiGridSolverV2B : MultiGridSolverHIP { MultiGridSolverV2B(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 2, 0, true) {} };
+struct MultiGridSolverV3B : MultiGridSolverHIP { MultiGridSolverV3B(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 3, 0, true) {} };
+struct MultiGridSolverV4B : MultiGridSolverHIP { MultiGridSolverV4B(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 4, 0, true) {} };
+struct MultiGridSolverV5B : MultiGridSolverHIP { MultiGridSolverV5B(World &w, int it, double tol) : MultiGridSolverHIP(w, it, tol, 5, 0, true) {} };
 }  // namespace hip
 
 #endif

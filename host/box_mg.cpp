@@ -4,7 +4,8 @@
 // The particle species that produce rho in the reference are replaced by the deterministic
 // synthetic charge density used by this repository's benchmarks.
 //
-//   box_mg [n=41] [depth=2] [tol=1e-4] [--dump file] [--dump-ef file]
+//   box_mg [n=41] [depth=2] [tol=1e-4] [--b] [--dump file] [--dump-ef file]
+//   --b selects the reference's "B" solver variant (7-point restriction)
 //   depth 0 selects the plain Gauss-Seidel/SOR solver; --dump writes phi as raw fp64 [i][j][k],
 //   --dump-ef the electric field as raw fp64 [i][j][k][3]
 #include <chrono>
@@ -22,10 +23,12 @@ int main(int argc, char **argv)
     int n = 41, depth = 2;
     double tol = 1e-4;
     const char *dump = nullptr, *dump_ef = nullptr;
+    bool variant_b = false;
     int pos = 0;
     for (int a = 1; a < argc; a++) {
         if (!strcmp(argv[a], "--dump") && a + 1 < argc) dump = argv[++a];
         else if (!strcmp(argv[a], "--dump-ef") && a + 1 < argc) dump_ef = argv[++a];
+        else if (!strcmp(argv[a], "--b")) variant_b = true;
         else if (pos == 0) { n = atoi(argv[a]); pos++; }
         else if (pos == 1) { depth = atoi(argv[a]); pos++; }
         else if (pos == 2) { tol = atof(argv[a]); pos++; }
@@ -45,7 +48,7 @@ int main(int argc, char **argv)
                                           0.5 * std::sin(5 * pi * x) * std::sin(3 * pi * y) * std::sin(7 * pi * z));
                 }
         MultiGridSolverHIP *mg = depth == 0 ? new GaussSeidelSolverHIP(world, 100000, tol)
-                                            : new MultiGridSolverHIP(world, 10000, tol, depth);
+                                            : new MultiGridSolverHIP(world, 10000, tol, depth, 0, variant_b);
         PotentialSolver *solver = mg;  // used through the base pointer, like the reference driver
         auto t0 = std::chrono::high_resolution_clock::now();
         const bool ok = solver->solve();

@@ -55,7 +55,7 @@ typedef struct mg_handle mg_handle;
  *            :3298-3307, :3759-3770)
  *   omega   SOR factor, 1.4 in the reference (cpp/PotentialSolver.cpp:3786)
  *   device  HIP device ordinal
- *   flags   0, or MG_FLAG_KEEP_FINE_RESIDUAL */
+ *   flags   0, or MG_FLAG_* bits */
 typedef struct mg_config {
     int64_t n[3];
     double dh[3];
@@ -72,6 +72,11 @@ typedef struct mg_config {
  * with this flag the cycle uses separate residual and restriction kernels and
  * mg_get_level_array(h, 0, 0, ...) works.  Results are bit-identical either way. */
 #define MG_FLAG_KEEP_FINE_RESIDUAL 1
+/* Restrict with the 7-point weights of the reference's "B" classes
+ * (MultiGridSolverB..V5B, cpp/PotentialSolver.cpp:704-715, :1991-2002) instead
+ * of the 27-point full weighting.  The cycle then runs the separate residual and
+ * restriction kernels (R_h is stored). */
+#define MG_FLAG_RESTRICT_7PT 2
 
 /* Accumulated device time per operator, measured with HIP events on the
  * handle's stream while profiling is on (mg_set_profiling).  Index with
@@ -107,6 +112,10 @@ int mg_device_count(void);
  * deeper: 1 fine sweep, 5 per intermediate level, 50 on the coarsest). */
 int mg_default_config(mg_config *cfg, int64_t ni, int64_t nj, int64_t nk,
                       const double dh[3], int depth);
+/* The same for the "B" classes (cpp/PotentialSolver.h:274-350): MG_FLAG_RESTRICT_7PT,
+ * and for depth 5 the schedule 1,2,3,4,5,50 (cpp/PotentialSolver.cpp:1928-1939). */
+int mg_default_config_b(mg_config *cfg, int64_t ni, int64_t nj, int64_t nk,
+                        const double dh[3], int depth);
 int mg_create(const mg_config *cfg, mg_handle **out);
 int mg_destroy(mg_handle *h);
 
@@ -193,6 +202,10 @@ int mg_op_residual_restrict(int device, const int64_t n[3], const double dh[3],
  * read-modify-written: entries the loop does not reach keep their values. */
 int mg_op_restrict27(int device, const int64_t n_fine[3], const double *R_fine,
                      double *R_coarse);
+/* The "B" classes' 7-point restriction (cpp/PotentialSolver.cpp:704-715); same array
+ * conventions as mg_op_restrict27. */
+int mg_op_restrict7(int device, const int64_t n_fine[3], const double *R_fine,
+                    double *R_coarse);
 /* Trilinear prolongation, overwriting eps_fine on 0..n-2 per axis
  * (cpp/PotentialSolver.cpp:4170-4206).  n = size of the fine level (loop
  * bound), fine_dims = dims of eps_fine (n for the finest level, n+1 for a

@@ -105,6 +105,7 @@ struct mg_handle {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bool have_rho = false, have_phi = false;
     bool fused_residual = true;  // R_0 never stored (default); false with MG_FLAG_KEEP_FINE_RESIDUAL
+    bool restrict7 = false;      // MG_FLAG_RESTRICT_7PT: the "B" classes' restriction
     bool correction_pending = false;  // phi -= P(eps_1) of the last iteration not applied yet
     double last_ms = 0;
     // profiling
@@ -223,7 +224,10 @@ void enqueue_coarse_correction(mg_handle *h)
     const int L = h->L;
     for (int l = h->fused_residual ? 1 : 0; l < L; l++) {
         Prof p(h, MG_T_RESTRICT, 9.0 * (double)count3(h->lv[l].n));
-        mgk::restrict27(h->stream, h->lv[l].R, h->lv[l + 1].R, h->lv[l].n, IRange{0, h->lv[l + 1].n[0]});
+        if (h->restrict7)
+            mgk::restrict7(h->stream, h->lv[l].R, h->lv[l + 1].R, h->lv[l].n, IRange{0, h->lv[l + 1].n[0]});
+        else
+            mgk::restrict27(h->stream, h->lv[l].R, h->lv[l + 1].R, h->lv[l].n, IRange{0, h->lv[l + 1].n[0]});
     }
     for (int l = L; l >= 1; l--) {
         Level &v = h->lv[l];
@@ -322,6 +326,17 @@ int mg_device_count(void)
     return count;
 }
 
+int mg_default_config_b(mg_config *cfg, int64_t ni, int64_t nj, int64_t nk, const double dh[3], int depth)
+{
+    int rc = mg_default_config(cfg, ni, nj, nk, dh, depth);
+    if (rc) return rc;
+    if (depth < 1) return fail(MG_ERR_INVALID, "the B solvers need at least one coarse grid");
+    cfg->flags |= MG_FLAG_RESTRICT_7PT;
+    if (depth >= 5)  // 1, 2, 3, 4, 5, 50 (cpp/PotentialSolver.cpp:1928-1939); deeper: 5 on the added levels
+        for (int l = 1; l < depth; l++) cfg->nu[l] = l + 1 < 5 ? l + 1 : 5;
+    return MG_OK;
+}
+
 int mg_default_config(mg_config *cfg, int64_t ni, int64_t nj, int64_t nk, const double dh[3], int depth)
 {
     if (!cfg || !dh) return fail(MG_ERR_INVALID, "null argument");
@@ -354,6 +369,8 @@ int mg_create(const mg_config *cfg, mg_handle **out)
     }
     for (int l = 0; l <= L; l++)
         if (cfg->nu[l] < 0 || cfg->nu[l] > 100000) return fail(MG_ERR_INVALID, "nu[%d]=%d out of range", l, cfg->nu[l]);
+    if (cfg->flags & ~(MG_FLAG_KEEP_FINE_RESIDUAL | MG_FLAG_RESTRICT_7PT))
+        return fail(MG_ERR_INVALID, "unknown flag bits 0x%x", (unsigned)cfg->flags);
     int rc = select_device(cfg->device);
     if (rc) return rc;
 
@@ -361,7 +378,9 @@ int mg_create(const mg_config *cfg, mg_handle **out)
     if (!h) return fail(MG_ERR_NOMEM, "host allocation failed");
     h->cfg = *cfg;
     h->L = L;
-    h->fused_residual = L >= 1 && !(cfg->flags & MG_FLAG_KEEP_FINE_RESIDUAL);
+    h->restrict7 = (cfg->flags & MG_FLAG_RESTRICT_7PT) != 0;
+    // the fused residual+restriction kernel implements the 27-point weights only
+    h->fused_residual = L >= 1 && !(cfg->flags & MG_FLAG_KEEP_FINE_RESIDUAL) && !h->restrict7;
     if (getenv("MG_KEEP_RF")) h->fused_residual = false;  // A/B measurements
     memset(&h->timers, 0, sizeof(h->timers));
     memset(h->lv, 0, sizeof(h->lv));
@@ -805,6 +824,22 @@ int mg_op_restrict27(int device, const int64_t n_fine[3], const double *R_fine, 
     TRY(sc.view(&vf, n_fine, R_fine));
     TRY(sc.view(&vc, nc, R_coarse));
     mgk::restrict27(nullptr, vf, vc, n_fine, IRange{0, nc[0]});
+    HIP_TRY(hipGetLastError());
+    return sc.download(vc, R_coarse);
+}
+
+int mg_op_restrict7(int device, const int64_t n_fine[3], const double *R_fine, double *R_coarse)
+{
+    if (!R_fine || !R_coarse) return fail(MG_ERR_INVALID, "null argument");
+    TRY(check_dims(n_fine, "mg_op_restrict7", 2));
+    TRY(select_device(device));
+    int64_t nc[3];
+    for (int a = 0; a < 3; a++) nc[a] = n_fine[a] >> 1;
+    Scratch sc;
+    View vf, vc;
+    TRY(sc.view(&vf, n_fine, R_fine));
+    TRY(sc.view(&vc, nc, R_coarse));
+    mgk::restrict7(nullptr, vf, vc, n_fine, IRange{0, nc[0]});
     HIP_TRY(hipGetLastError());
     return sc.download(vc, R_coarse);
 }

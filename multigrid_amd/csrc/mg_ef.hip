@@ -57,16 +57,18 @@ __global__ __launch_bounds__(256) void k_compute_ef(View phi, double *__restrict
     const bool jface = jc == 0 || jc == nj - 1, kface = kc == 0 || kc == nk - 1;
 
     const double *p = phi.p;
-    double um1 = p[phi.at(clampi(lo - 1, 0, ni - 1), jc, kc)];
+    // prefetches past the range stay inside the planes the (possibly slab) view stores
+    const int64_t plo = phi.i0, phi_last = phi.i_end() - 1;
+    double um1 = p[phi.at(clampi(lo - 1, plo, phi_last), jc, kc)];
     double u0 = p[phi.at(lo, jc, kc)];
-    double up1 = p[phi.at(clampi(lo + 1, 0, ni - 1), jc, kc)];
+    double up1 = p[phi.at(clampi(lo + 1, plo, phi_last), jc, kc)];
     const int64_t row_doubles = nk * 3;
     const int64_t seg0 = (int64_t)kt * EF_COLS * 3;                       // first double of this window in a row
     const int64_t seg_len = ((nk - (int64_t)kt * EF_COLS < EF_COLS) ? nk - (int64_t)kt * EF_COLS : EF_COLS) * 3;
 
     int buf = 0;
     for (int64_t i = lo; i < hi; i++, buf ^= 1) {
-        const double unext = p[phi.at(clampi(i + 2, 0, ni - 1), jc, kc)];  // becomes up1 next plane
+        const double unext = p[phi.at(clampi(i + 2, plo, phi_last), jc, kc)];  // becomes up1 next plane
         const double vjm = p[phi.at(i, jm1, kc)], vjp = p[phi.at(i, jp1, kc)];
         const double vkm = p[phi.at(i, jc, km1)], vkp = p[phi.at(i, jc, kp1)];
         double vi2 = 0, vj2 = 0, vk2 = 0;

@@ -159,6 +159,8 @@ int64_t sumsq_partials(int64_t count);
 void sumsq(hipStream_t s, const double *x, int64_t count, double *partials);
 // Coarse planes rc of Rc = restrict27(Rf); nf = size of the fine level.
 void restrict27(hipStream_t s, View Rf, View Rc, const int64_t nf[3], IRange rc);
+// The same with the 7-point weights of the reference's "B" solver classes.
+void restrict7(hipStream_t s, View Rf, View Rc, const int64_t nf[3], IRange rc);
 // trilinear prolongation of ec onto planes r of ef (within 0..n-2 per axis)
 void prolong(hipStream_t s, View ec, View ef, const int64_t n[3], IRange r);
 // phi -= prolong(ec) on planes r (within 1..n-2 per axis)

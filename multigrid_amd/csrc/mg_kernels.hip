@@ -210,6 +210,25 @@ __global__ __launch_bounds__(256) void k_restrict27(View Rf, View Rc, int64_t Il
     Rc.p[Rc.at(I, J, K)] = v;
 }
 
+// 7-point restriction of the "B" solver family (reference cpp/PotentialSolver.cpp:704-715,
+// :1991-2002): terms summed left to right, then / 12.0; injection where an index is 0.
+__global__ __launch_bounds__(256) void k_restrict7(View Rf, View Rc, int64_t Ilo)
+{
+    const int64_t K = (int64_t)blockIdx.x * kBX + threadIdx.x;
+    const int64_t J = (int64_t)blockIdx.y * kBY + threadIdx.y;
+    const int64_t I = Ilo + blockIdx.z;
+    if (K >= Rc.d[2] || J >= Rc.d[1]) return;
+    const double *f = Rf.p + Rf.at(2 * I, 2 * J, 2 * K);
+    double v;
+    if (I == 0 || J == 0 || K == 0) {
+        v = f[0];
+    } else {
+        const int64_t si = Rf.si, sj = Rf.sj;
+        v = (f[-si] + 2 * f[0] + f[si] + f[-sj] + 2 * f[0] + f[sj] + f[-1] + 2 * f[0] + f[1]) / 12.0;
+    }
+    Rc.p[Rc.at(I, J, K)] = v;
+}
+
 // Prolongation by coarse cell: a thread takes the eight coarse corner values of
 // cell (I,J,K) and produces the eight fine points (2I+di, 2J+dj, 2K+dk), as four
 // 16-byte pairs along k.  The eight parity cases of the reference
@@ -225,8 +244,9 @@ __global__ __launch_bounds__(256) void k_prolong(View ec, View out, int64_t nI, 
     const int64_t K = (int64_t)blockIdx.x * kBX + threadIdx.x;
     const int64_t J = (int64_t)blockIdx.y * kBY + threadIdx.y;
     const int64_t I = (ilo >> 1) + blockIdx.z;  // cells whose fine planes 2I, 2I+1 meet [ilo, ihi)
-    // fine points 0..n-2 per axis are written; cell K covers k = 2K, 2K+1
-    if (2 * K > nK - 2 || 2 * J > nJ - 2) return;
+    // fine points 0..n-2 per axis are written; cell K covers k = 2K, 2K+1.  A cell past that
+    // range writes nothing and its far corners lie outside the coarse array: it must not load.
+    if (2 * K > nK - 2 || 2 * J > nJ - 2 || 2 * I > nI - 2) return;
     const double *c = ec.p + ec.at(I, J, K);
     const int64_t si = ec.si, sj = ec.sj;
     const double c000 = c[0], c100 = c[si], c010 = c[sj], c110 = c[si + sj];
@@ -470,6 +490,14 @@ void restrict27(hipStream_t s, View Rf, View Rc, const int64_t nf[3], IRange rc)
     if (rc.hi <= rc.lo) return;
     hipLaunchKernelGGL(k_restrict27, grid_for(Rc.d[2], Rc.d[1], rc.hi - rc.lo), dim3(kBX, kBY), 0, s, Rf,
                        Rc, rc.lo);
+}
+
+void restrict7(hipStream_t s, View Rf, View Rc, const int64_t nf[3], IRange rc)
+{
+    (void)nf;
+    if (rc.hi <= rc.lo) return;
+    hipLaunchKernelGGL(k_restrict7, grid_for(Rc.d[2], Rc.d[1], rc.hi - rc.lo), dim3(kBX, kBY), 0, s, Rf, Rc,
+                       rc.lo);
 }
 
 static void launch_prolong(hipStream_t s, bool correct, View ec, View out, const int64_t n[3], IRange r)

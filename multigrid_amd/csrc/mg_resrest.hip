@@ -197,14 +197,21 @@ struct Geometry {
     unsigned grid;
 };
 
+// window rows: 32 (256 threads) or 64 (512 threads; fewer halo rows re-read per owned row)
+int window_rows()
+{
+    static const int wj = [] { const char *e = getenv("MG_RR_WJ"); return e ? atoi(e) : 32; }();
+    return wj == 64 ? 64 : 32;
+}
+
 Geometry geometry(const int64_t n[3], IRange r)
 {
-    constexpr int TJ = 28, TK = 60;
+    const int TJ = window_rows() - 4, TK = 60;
     Geometry g;
     const int64_t planes = r.hi - r.lo;
     g.tiles_j = (int)((n[1] + TJ - 1) / TJ);
     g.tiles_k = (int)((n[2] + TK - 1) / TK);
-    int nchunks = pick_chunks((int64_t)g.tiles_j * g.tiles_k, planes, 3, 2);
+    int nchunks = pick_chunks((int64_t)g.tiles_j * g.tiles_k, planes, 3, 2, window_rows() == 64 ? 256 : 512);
     static const int want = [] { const char *e = getenv("MG_RR_CHUNKS"); return e ? atoi(e) : 0; }();
     if (want > 0) nchunks = want;
     int CI = (int)((planes + nchunks - 1) / nchunks);
@@ -228,10 +235,14 @@ void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const 
     const Geometry g = geometry(n, r);
     static const int threads = [] { const char *e = getenv("MG_RR_NT"); return e ? atoi(e) : 256; }();
     static const int depth = [] { const char *e = getenv("MG_RR_D"); return e ? atoi(e) : 2; }();
-#define LAUNCH(D, RF, NT)                                                                             \
-    hipLaunchKernelGGL((k_residual_restrict<32, 32, D, RF, NT>), dim3(g.grid), dim3(NT), 0, s, phi, b, \
+#define LAUNCHW(WJ, D, RF, NT)                                                                        \
+    hipLaunchKernelGGL((k_residual_restrict<WJ, 32, D, RF, NT>), dim3(g.grid), dim3(NT), 0, s, phi, b, \
                        Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi)
-    if (Rf.p) {
+#define LAUNCH(D, RF, NT) LAUNCHW(32, D, RF, NT)
+    if (window_rows() == 64) {
+        if (Rf.p) LAUNCHW(64, 2, true, 512);
+        else LAUNCHW(64, 2, false, 512);
+    } else if (Rf.p) {
         LAUNCH(2, true, 256);
     } else if (threads == 512) {
         if (depth == 1) LAUNCH(1, false, 512);
@@ -241,6 +252,7 @@ void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const 
         else LAUNCH(2, false, 256);
     }
 #undef LAUNCH
+#undef LAUNCHW
 }
 
 }  // namespace mgk

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libmg_hip.so")
 MG_MAX_LEVELS = 12
 MG_ABI_VERSION = 1
 MG_FLAG_KEEP_FINE_RESIDUAL = 1
+MG_FLAG_RESTRICT_7PT = 2
 
 TIMER_KINDS = ("smooth_fine", "residual", "restrict", "smooth_coarse", "prolong",
                "prolong_correct", "norm", "ef")
@@ -55,6 +56,7 @@ SYMBOLS = {
     "mg_last_error": (C.c_char_p, []),
     "mg_device_count": (C.c_int, []),
     "mg_default_config": (C.c_int, [C.POINTER(MgConfig), C.c_int64, C.c_int64, C.c_int64, _f64x3, C.c_int]),
+    "mg_default_config_b": (C.c_int, [C.POINTER(MgConfig), C.c_int64, C.c_int64, C.c_int64, _f64x3, C.c_int]),
     "mg_create": (C.c_int, [C.POINTER(MgConfig), C.POINTER(_H)]),
     "mg_destroy": (C.c_int, [_H]),
     "mg_set_rho": (C.c_int, [_H, _dp]),
@@ -75,6 +77,7 @@ SYMBOLS = {
     "mg_op_residual": (C.c_int, [C.c_int, _i64x3, _f64x3, _dp, _dp, _dp, _dp]),
     "mg_op_residual_restrict": (C.c_int, [C.c_int, _i64x3, _f64x3, _dp, _dp, _dp, _dp, _dp]),
     "mg_op_restrict27": (C.c_int, [C.c_int, _i64x3, _dp, _dp]),
+    "mg_op_restrict7": (C.c_int, [C.c_int, _i64x3, _dp, _dp]),
     "mg_op_prolong": (C.c_int, [C.c_int, _i64x3, _i64x3, _dp, _dp]),
     "mg_op_correct": (C.c_int, [C.c_int, C.c_int64, _dp, _dp]),
     "mg_op_prolong_correct": (C.c_int, [C.c_int, _i64x3, _dp, _dp]),
@@ -144,9 +147,10 @@ def device_count():
     return load().mg_device_count()
 
 
-def default_config(n, dh, depth, device=0):
+def default_config(n, dh, depth, device=0, variant_b=False):
     cfg = MgConfig()
-    _check(load().mg_default_config(C.byref(cfg), n[0], n[1], n[2], _f64x3(*dh), depth))
+    f = load().mg_default_config_b if variant_b else load().mg_default_config
+    _check(f(C.byref(cfg), n[0], n[1], n[2], _f64x3(*dh), depth))
     cfg.device = device
     return cfg
 
@@ -154,10 +158,10 @@ def default_config(n, dh, depth, device=0):
 class Handle:
     """Owns one mg_handle (one reference MultiGridSolverVn object's worth of state)."""
 
-    def __init__(self, n, dh, depth, nu=None, omega=None, device=0, flags=0):
+    def __init__(self, n, dh, depth, nu=None, omega=None, device=0, flags=0, variant_b=False):
         self.n = tuple(int(a) for a in n)
         self.depth = depth
-        cfg = default_config(self.n, dh, depth, device)
+        cfg = default_config(self.n, dh, depth, device, variant_b)
         if nu is not None:
             if len(nu) != depth + 1:
                 raise ValueError("nu must have depth+1 entries")
@@ -165,7 +169,7 @@ class Handle:
                 cfg.nu[l] = v
         if omega is not None:
             cfg.omega = omega
-        cfg.flags = flags
+        cfg.flags |= flags
         self.cfg = cfg
         self._h = _H()
         _check(load().mg_create(C.byref(cfg), C.byref(self._h)))
@@ -288,6 +292,14 @@ def op_restrict27(Rf, Rc=None, device=0):
     if Rc is None:
         Rc = np.zeros(tuple(s >> 1 for s in Rf.shape))
     _check(load().mg_op_restrict27(device, _i64x3(*Rf.shape), pf, _out(Rc)))
+    return Rc
+
+
+def op_restrict7(Rf, Rc=None, device=0):
+    Rf, pf = _in(Rf)
+    if Rc is None:
+        Rc = np.zeros(tuple(s >> 1 for s in Rf.shape))
+    _check(load().mg_op_restrict7(device, _i64x3(*Rf.shape), pf, _out(Rc)))
     return Rc
 
 

@@ -170,6 +170,27 @@ void orc_restrict27(const double *Rf, const int64_t nf[3], double *Rc, const int
             }
 }
 
+/* The "B" solver family's restriction (MultiGridSolverB..V5B, e.g.
+ * cpp/PotentialSolver.cpp:704-715, :1991-2002): same loop bounds and injection rule as above,
+ * interior value = (R[i-1]+2R+R[i+1] + R[j-1]+2R+R[j+1] + R[k-1]+2R+R[k+1]) / 12.0, summed
+ * left to right. */
+void orc_restrict7(const double *Rf, const int64_t nf[3], double *Rc, const int64_t nc[3])
+{
+    const int64_t si = nf[1] * nf[2], sj = nf[2];
+    for (int64_t i = 0; i < nf[0] - 1; i += 2)
+        for (int64_t j = 0; j < nf[1] - 1; j += 2)
+            for (int64_t k = 0; k < nf[2] - 1; k += 2) {
+                const int64_t p = IDX(i, j, k, nf[1], nf[2]);
+                const int64_t q = IDX(i / 2, j / 2, k / 2, nc[1], nc[2]);
+                if (i == 0 || j == 0 || k == 0)
+                    Rc[q] = Rf[p];
+                else
+                    Rc[q] = (Rf[p - si] + 2 * Rf[p] + Rf[p + si] +
+                             Rf[p - sj] + 2 * Rf[p] + Rf[p + sj] +
+                             Rf[p - 1] + 2 * Rf[p] + Rf[p + 1]) / 12.0;
+            }
+}
+
 /* Trilinear prolongation e_c (dims cn) -> e_f (dims fn), OVERWRITING e_f on
  * 0..n-2 per axis where n[3] is the fine level's size; zero where any index is
  * 0; everything outside 0..n-2 is left untouched
@@ -273,6 +294,7 @@ int orc_gs_solve(double *phi, const double *rho, const int64_t n[3], const doubl
  * all zero at construction and never cleared afterwards. */
 typedef struct {
     int depth;                       /* L = number of coarse grids */
+    int restrict7;                   /* 1: the "B" classes' 7-point restriction */
     int nu[ORC_MAX_LEVELS];          /* sweeps per level, nu[0] on the fine grid */
     double omega;
     double dh[3];
@@ -323,6 +345,7 @@ void orc_solver_reset(orc_solver *s)
     }
 }
 
+void orc_solver_set_restrict7(orc_solver *s, int on) { s->restrict7 = on != 0; }
 double *orc_solver_R(orc_solver *s, int l) { return s->R[l]; }
 double *orc_solver_eps(orc_solver *s, int l) { return s->eps[l]; }
 
@@ -354,7 +377,10 @@ int orc_solve(orc_solver *s, double *phi, const double *rho, unsigned max_it,
         L2 = sqrt(sum / (double)N0);
         if (l2_hist) l2_hist[it] = L2;
         if (L2 < tol) { converged = 1; it++; break; }
-        for (int l = 0; l < L; l++) orc_restrict27(s->R[l], s->n[l], s->R[l + 1], s->n[l + 1]);
+        for (int l = 0; l < L; l++) {
+            if (s->restrict7) orc_restrict7(s->R[l], s->n[l], s->R[l + 1], s->n[l + 1]);
+            else orc_restrict27(s->R[l], s->n[l], s->R[l + 1], s->n[l + 1]);
+        }
         smooth(s->eps[L], s->en[L], s->R[L], s->n[L], s->n[L], c[L], s->omega, s->nu[L], 0);
         for (int l = L - 1; l >= 1; l--) {
             orc_prolong(s->eps[l + 1], s->en[l + 1], s->eps[l], s->en[l], s->n[l]);

@@ -72,6 +72,10 @@ def lib():
         L.orc_sumsq.restype = C.c_double
         L.orc_restrict27.argtypes = [_dp, _i64x3, _dp, _i64x3]
         L.orc_restrict27.restype = None
+        L.orc_restrict7.argtypes = [_dp, _i64x3, _dp, _i64x3]
+        L.orc_restrict7.restype = None
+        L.orc_solver_set_restrict7.argtypes = [C.c_void_p, C.c_int]
+        L.orc_solver_set_restrict7.restype = None
         L.orc_prolong.argtypes = [_dp, _i64x3, _dp, _i64x3, _i64x3]
         L.orc_prolong.restype = None
         L.orc_correct.argtypes = [_dp, _dp, C.c_int64]
@@ -157,6 +161,14 @@ def restrict27(Rf, Rc=None):
     return Rc
 
 
+def restrict7(Rf, Rc=None):
+    """The "B" classes' 7-point restriction; Rc (dims nf>>1) is created zero-filled if not given."""
+    if Rc is None:
+        Rc = np.zeros(tuple(s >> 1 for s in Rf.shape))
+    lib().orc_restrict7(_p(Rf), _dims(Rf), _p(Rc), _dims(Rc))
+    return Rc
+
+
 def prolong(ec, ef, n):
     """Overwrite ef on 0..n-2 per axis with the trilinear interpolant of ec."""
     lib().orc_prolong(_p(ec), _dims(ec), _p(ef), _dims(ef), _i64x3(*n))
@@ -192,8 +204,11 @@ SCHEDULES = {  # nu[0..L] of the reference classes (cpp/PotentialSolver.cpp:2422
 }
 
 
-def schedule(depth):
-    """Reference schedule for depth 1..5; beyond that the V5 pattern extended."""
+def schedule(depth, variant_b=False):
+    """Reference schedule for depth 1..5; beyond that the V5 pattern extended.  variant_b: the
+    "B" classes, whose V5B runs 1,2,3,4,5,50 (cpp/PotentialSolver.cpp:1928-1939)."""
+    if variant_b and depth >= 5:
+        return (1,) + tuple(min(l + 1, 5) for l in range(1, depth)) + (50,)
     if depth in SCHEDULES:
         return SCHEDULES[depth]
     return (1,) + (5,) * (depth - 1) + (50,)
@@ -202,17 +217,18 @@ def schedule(depth):
 class Solver:
     """The state a reference MultiGridSolver* object keeps between solve() calls."""
 
-    def __init__(self, n0, dh, depth, nu=None, omega=1.4):
+    def __init__(self, n0, dh, depth, nu=None, omega=1.4, variant_b=False):
         self.n0 = tuple(int(a) for a in n0)
         self.dh = tuple(float(a) for a in dh)
         self.depth = depth
-        self.nu = tuple(nu) if nu is not None else schedule(depth)
+        self.nu = tuple(nu) if nu is not None else schedule(depth, variant_b)
         assert len(self.nu) == depth + 1
         self.omega = omega
         arr = (C.c_int * (depth + 1))(*self.nu)
         self._h = lib().orc_solver_new(_i64x3(*self.n0), _f64x3(*self.dh), depth, arr, omega)
         if not self._h:
             raise ValueError("oracle: invalid size/depth")
+        lib().orc_solver_set_restrict7(self._h, int(variant_b))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -120,3 +120,81 @@ def test_gs_on_a_multigrid_handle(gpu, orc):
         h.set_phi(np.zeros(n))
         h.gs_solve(10, 0.0)
         assert_bit_equal(h.get_phi(), want, "GS on MG handle")
+
+
+@pytest.mark.parametrize("lo,hi", [(0, 7), (6, 14), (13, 21), (0, 21)], ids=str)
+def test_compute_ef_on_a_slab(gpu, orc, lo, hi):
+    """mg_dev_compute_ef on planes [lo,hi) of a slab that stores one halo plane per side (plus
+    what the one-sided face formulas reach) equals the rows of the whole-array result."""
+    import ctypes as C
+    import torch
+    n = (21, 30, 37)
+    dh = (0.01, 0.02, 0.03)
+    phi = phi_like(n, rng(24))
+    want = orc.compute_ef(phi, dh)[lo:hi]
+    s_lo, s_hi = max(lo - 1, 0), min(hi + 1, n[0])
+    if lo == 0:
+        s_hi = max(s_hi, 3)
+    if hi == n[0]:
+        s_lo = min(s_lo, n[0] - 3)
+    pitch = (n[2] + 1) & ~1
+    dev = torch.device("cuda", 0)
+    slab = torch.zeros((s_hi - s_lo, n[1], pitch), dtype=torch.float64, device=dev)
+    slab[:, :, :n[2]] = torch.from_numpy(phi[s_lo:s_hi]).to(dev)
+    ef = torch.full((hi - lo, n[1], n[2], 3), float("nan"), dtype=torch.float64, device=dev)
+    arr = gpu.MgDevArray(slab.data_ptr(), slab.shape[0], n[1], n[2], s_lo)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    gpu._check(gpu.load().mg_dev_compute_ef(stream, C.byref(arr), C.c_void_p(ef.data_ptr()), lo,
+                                           (C.c_int64 * 3)(*n), (C.c_double * 3)(*dh), lo, hi))
+    torch.cuda.synchronize(dev)
+    assert_bit_equal(ef.cpu().numpy(), want, "slab ef")
+    # a slab without the halo plane is refused, not read out of bounds
+    if lo > 0:
+        short = gpu.MgDevArray(slab.data_ptr(), slab.shape[0], n[1], n[2], s_lo + 1)
+        with pytest.raises(gpu.MgError):
+            gpu._check(gpu.load().mg_dev_compute_ef(stream, C.byref(short), C.c_void_p(ef.data_ptr()), lo,
+                                                   (C.c_int64 * 3)(*n), (C.c_double * 3)(*dh), lo, hi))
+
+
+B_SHAPES = [(4, 5, 6), (17, 17, 17), (20, 20, 20), (33, 21, 45), (64, 64, 64), (129, 129, 129)]
+
+
+@pytest.mark.parametrize("shape", B_SHAPES, ids=str)
+def test_restrict7_operator(gpu, orc, shape):
+    """The "B" classes' 7-point restriction (cpp/PotentialSolver.cpp:704-715)."""
+    g = rng(31)
+    Rf = phi_like(shape, g)
+    Rc0 = phi_like(tuple(s >> 1 for s in shape), g)  # entries the loop does not reach must survive
+    assert_bit_equal(gpu.op_restrict7(Rf, Rc0.copy()), orc.restrict7(Rf, Rc0.copy()), "restrict7")
+
+
+@pytest.mark.parametrize("n,depth", [(41, 1), (41, 2), (129, 3), (129, 4), (257, 5)])
+def test_b_variant_cycles_match_rb_oracle_bit_for_bit(gpu, orc, n, depth):
+    N = (n, n, n)
+    dh, rho = orc.main_extents_dh(N), orc.synthetic_rho(N)
+    cycles = 3
+    want = np.zeros(N)
+    s = orc.Solver(N, dh, depth, variant_b=True)
+    ok, cyc, l2, hist = s.solve(want, rho, cycles, 0.0, rb=True)
+    with gpu.Handle(N, dh, depth, variant_b=True) as h:
+        assert list(h.cfg.nu[:depth + 1]) == list(orc.schedule(depth, variant_b=True))
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        got_hist = [h.vcycles(1) for _ in range(cycles)]
+        assert_bit_equal(h.get_phi(), want, "phi (B variant)")
+        for l in range(1, depth + 1):
+            assert_bit_equal(h.level_array("R", l), s.R(l), f"R_{l} (B variant)")
+    assert got_hist == pytest.approx(list(hist), rel=1e-11)
+
+
+def test_b_variant_converges_to_the_same_solution(gpu, orc):
+    N = (65, 65, 65)
+    dh, rho = orc.main_extents_dh(N), orc.synthetic_rho(N)
+    ref = np.zeros(N)
+    assert orc.Solver(N, dh, 3, variant_b=True).solve(ref, rho, 10000, 1e-6)[0]   # lexicographic, B
+    with gpu.Handle(N, dh, 3, variant_b=True) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        ok, cyc, l2 = h.solve(10000, 1e-6)
+        assert ok
+        assert rel_l2(h.get_phi(), ref) <= 1e-6

@@ -73,3 +73,26 @@ def test_gs_loop_stops_on_a_tested_iteration_and_agrees_with_multigrid(orc):
     rb = np.zeros(n)
     ok_rb, its_rb, _ = orc.gs_solve(rb, rho, dh, 20000, 1e-7, rb=True)
     assert ok_rb and np.linalg.norm(rb - gs) / np.linalg.norm(gs) < 1e-7
+
+
+def test_restrict7_weights_and_b_variant_fixed_point(orc):
+    """(1+2+1)*3/12 = 1: a constant field restricts to itself; injection where an index is 0; and
+    the B cycle (cpp/PotentialSolver.cpp:620-816) converges to the fixed point of the standard one."""
+    import numpy as np
+    Rf = np.full((9, 11, 13), 2.5)
+    Rc = orc.restrict7(Rf)
+    assert np.array_equal(Rc, np.full((4, 5, 6), 2.5))
+    g = np.random.default_rng(5)
+    Rf = g.uniform(-1, 1, size=(9, 9, 9))
+    Rc = orc.restrict7(Rf)
+    assert Rc[0, 2, 3] == Rf[0, 4, 6] and Rc[2, 0, 1] == Rf[4, 0, 2]
+    c = Rf[4, 4, 4]
+    want = (Rf[3, 4, 4] + 2 * c + Rf[5, 4, 4] + Rf[4, 3, 4] + 2 * c + Rf[4, 5, 4] + Rf[4, 4, 3] + 2 * c + Rf[4, 4, 5]) / 12.0
+    assert Rc[2, 2, 2] == want
+    n = (33, 33, 33)
+    dh, rho = orc.main_extents_dh(n), orc.synthetic_rho(n)
+    a, b = np.zeros(n), np.zeros(n)
+    assert orc.Solver(n, dh, 2).solve(a, rho, 2000, 1e-7)[0]
+    assert orc.Solver(n, dh, 2, variant_b=True).solve(b, rho, 2000, 1e-7)[0]
+    assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-7
+    assert orc.schedule(5, variant_b=True) == (1, 2, 3, 4, 5, 50)
