@@ -72,31 +72,41 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
             return *reinterpret_cast<const d2 *>(v.p + v.at(ic, j, kkc));
         };
 
-        // Own rows: planes p-1, p, p+1 and D planes in flight.  The rows above and below the
-        // block (hN, hS) and the right-hand side are needed at plane p only and are cache hits or
-        // streamed once, so they are requested just one plane ahead: fewer live registers.
-        d2 um1[Q], u0[Q], up1[Q], uf[D][Q], hN0, hS0, hNn, hSn, b0[Q], bn[Q];
+        // Own rows: planes p-1, p, p+1 and D planes in flight.  The rows above and below the block
+        // (hN, hS) and the right-hand side are needed at plane p only, but they too are requested
+        // D planes ahead: loads return in order, so waiting for a value requested one plane ago
+        // would also wait for everything requested before it and shorten the prefetch to one plane.
+        d2 um1[Q], u0[Q], up1[Q], uf[D][Q], hN0, hS0, hNf[D], hSf[D], b0[Q], bf[D][Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             um1[q] = load(phi, ia - 2, q);
             u0[q] = load(phi, ia - 1, q);
             up1[q] = load(phi, ia, q);
-#pragma unroll
-            for (int d = 0; d + 1 < D; d++) uf[d][q] = load(phi, ia + 1 + d, q);
             b0[q] = load(b, ia - 1, q);
+#pragma unroll
+            for (int d = 0; d + 1 < D; d++) {
+                uf[d][q] = load(phi, ia + 1 + d, q);
+                bf[d][q] = load(b, ia + d, q);
+            }
         }
         hN0 = load(phi, ia - 1, -1);
         hS0 = load(phi, ia - 1, Q);
+#pragma unroll
+        for (int d = 0; d + 1 < D; d++) {
+            hNf[d] = load(phi, ia + d, -1);
+            hSf[d] = load(phi, ia + d, Q);
+        }
 
         for (int p = ia - 1; p < ib; p++) {
             const int pl = min(p + 1 + D, ib);
+            const int pb = min(p + D, ib);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
                 uf[D - 1][q] = load(phi, pl, q);
-                bn[q] = load(b, p + 1, q);
+                bf[D - 1][q] = load(b, pb, q);
             }
-            hNn = load(phi, p + 1, -1);
-            hSn = load(phi, p + 1, Q);
+            hNf[D - 1] = load(phi, pb, -1);
+            hSf[D - 1] = load(phi, pb, Q);
 
             if (p >= 0) {
                 double(*S)[WK] = ring[p % 3];
@@ -174,10 +184,17 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
                 up1[q] = uf[0][q];
 #pragma unroll
                 for (int d = 0; d + 1 < D; d++) uf[d][q] = uf[d + 1][q];
-                b0[q] = bn[q];
+                b0[q] = bf[0][q];
+#pragma unroll
+                for (int d = 0; d + 1 < D; d++) bf[d][q] = bf[d + 1][q];
             }
-            hN0 = hNn;
-            hS0 = hSn;
+            hN0 = hNf[0];
+            hS0 = hSf[0];
+#pragma unroll
+            for (int d = 0; d + 1 < D; d++) {
+                hNf[d] = hNf[d + 1];
+                hSf[d] = hSf[d + 1];
+            }
         }
     }
     // workgroup partial sum, fixed order
@@ -197,21 +214,23 @@ struct Geometry {
     unsigned grid;
 };
 
-// window rows: 32 (256 threads) or 64 (512 threads; fewer halo rows re-read per owned row)
-int window_rows()
+// window rows: 32 (256 threads) or 64 (512 threads; fewer halo rows re-read per owned row, pays
+// once a plane has enough windows to fill the chip).  MG_RR_WJ=32|64 overrides (A/B runs).
+int window_rows(const int64_t n[3])
 {
-    static const int wj = [] { const char *e = getenv("MG_RR_WJ"); return e ? atoi(e) : 32; }();
-    return wj == 64 ? 64 : 32;
+    static const int wj = [] { const char *e = getenv("MG_RR_WJ"); return e ? atoi(e) : 0; }();
+    if (wj == 32 || wj == 64) return wj;
+    return n[1] >= 256 ? 64 : 32;
 }
 
 Geometry geometry(const int64_t n[3], IRange r)
 {
-    const int TJ = window_rows() - 4, TK = 60;
+    const int TJ = window_rows(n) - 4, TK = 60;
     Geometry g;
     const int64_t planes = r.hi - r.lo;
     g.tiles_j = (int)((n[1] + TJ - 1) / TJ);
     g.tiles_k = (int)((n[2] + TK - 1) / TK);
-    int nchunks = pick_chunks((int64_t)g.tiles_j * g.tiles_k, planes, 3, 2, window_rows() == 64 ? 256 : 512);
+    int nchunks = pick_chunks((int64_t)g.tiles_j * g.tiles_k, planes, 3, 2, window_rows(n) == 64 ? 256 : 512);
     static const int want = [] { const char *e = getenv("MG_RR_CHUNKS"); return e ? atoi(e) : 0; }();
     if (want > 0) nchunks = want;
     int CI = (int)((planes + nchunks - 1) / nchunks);
@@ -239,7 +258,7 @@ void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const 
     hipLaunchKernelGGL((k_residual_restrict<WJ, 32, D, RF, NT>), dim3(g.grid), dim3(NT), 0, s, phi, b, \
                        Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi)
 #define LAUNCH(D, RF, NT) LAUNCHW(32, D, RF, NT)
-    if (window_rows() == 64) {
+    if (window_rows(n) == 64) {
         if (Rf.p) LAUNCHW(64, 2, true, 512);
         else LAUNCHW(64, 2, false, 512);
     } else if (Rf.p) {

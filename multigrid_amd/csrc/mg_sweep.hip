@@ -342,7 +342,10 @@ static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec
 static void launch_sweep(hipStream_t s, View uin, View uout, View rhs, View ec, int load_op,
                          const int64_t n[3], Coef c, double omega, IRange r)
 {
-    static const int wj = env_int("MG_SWEEP_WJ", 32);
+    // 64-row windows (512 threads) re-read fewer halo rows per owned row; they pay once a plane has
+    // enough windows to fill the chip.  MG_SWEEP_WJ=32|64 overrides (A/B runs).
+    static const int forced = env_int("MG_SWEEP_WJ", 0);
+    const int wj = (forced == 32 || forced == 64) ? forced : (uin.d[1] >= 256 ? 64 : 32);
     if (wj == 64) launch_sweep_t<64, 512>(s, uin, uout, rhs, ec, load_op, n, c, omega, r);
     else launch_sweep_t<32, 256>(s, uin, uout, rhs, ec, load_op, n, c, omega, r);
 }
