@@ -36,7 +36,8 @@ struct IRange { int64_t lo, hi; };  // global planes [lo, hi)
 // the fastest-varying part of the workgroup index, so with a multiple of 8 chunks all windows
 // of a chunk land on one XCD and share its L2 (measured: 11 chunks instead of 8 cost the 513^3
 // sweep 13 %); multiples of 8 are preferred unless another count is clearly cheaper.
-inline int pick_chunks(int64_t tiles, int64_t planes, int extra, int align = 1, int64_t slots = 512)
+inline int pick_chunks(int64_t tiles, int64_t planes, int extra, int align = 1, int64_t slots = 512,
+                       bool prefer8 = true)
 {
     int best = 1, best8 = 0;
     double cost_best = 1e300, cost8 = 1e300;
@@ -49,8 +50,30 @@ inline int pick_chunks(int64_t tiles, int64_t planes, int extra, int align = 1, 
         if (c % 8 == 0 && cost < cost8 - 1e-9) { cost8 = cost; best8 = c; }
     }
     // a multiple of 8 keeps each chunk on one XCD; give that up only for a clear gain
-    return (best8 && cost8 <= 1.08 * cost_best) ? best8 : best;
+    return (prefer8 && best8 && cost8 <= 1.08 * cost_best) ? best8 : best;
 }
+
+// Workgroup -> (chunk, window) assignment of the marching kernels.  Workgroups are dealt to the
+// 8 XCDs round-robin by index (each XCD has its own L2), and neighbouring windows read the same
+// halo lines: `blocked` hands every XCD one contiguous run of the (chunk, window-row, window-column)
+// order, so a window's neighbours sit on the same L2 whatever the chunk count.  The grid is
+// padded to 8 x ceil(total/8) workgroups; item() returns -1 for the padding.
+struct WgOrder {
+    int total;    // chunks x windows
+    int blocked;  // 1: XCD-blocked order; 0: plain index (chunk fastest)
+    unsigned grid() const { return blocked ? 8u * (unsigned)((total + 7) / 8) : (unsigned)total; }
+#if defined(__HIPCC__)
+    __device__ int item(unsigned b) const
+    {
+        if (!blocked) return (int)b;
+        const int per = (total + 7) / 8;
+        const int o = (int)(b % 8u) * per + (int)(b / 8u);
+        return o < total ? o : -1;
+    }
+#endif
+};
+// MG_WG_ORDER=plain|blocked overrides the default (A/B runs).
+bool wg_order_blocked();
 
 // Row pitch used for every device array: rows start 16-byte aligned.
 inline int64_t pitch_for(int64_t nk) { return (nk + 1) & ~int64_t(1); }

@@ -390,6 +390,16 @@ static bool use_fused_sweep(const View &u)
     return u.d[0] >= 4 && u.d[1] >= min_dim && u.d[2] >= min_dim;
 }
 
+bool wg_order_blocked()
+{
+    static const int mode = [] {
+        const char *e = getenv("MG_WG_ORDER");
+        if (e && !strcmp(e, "plain")) return 0;
+        return 1;
+    }();
+    return mode == 1;
+}
+
 bool sweep_is_out_of_place(const View &u) { return use_fused_sweep(u); }
 
 int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c,

@@ -38,7 +38,7 @@ template <int WJ, int WKP, int D, bool STORE_RF, int NT>
 __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View Rf, View Rc, int nI,
                                                            Coef c, double *__restrict__ partials,
                                                            int CI, int nchunks, int tiles_k, int rlo,
-                                                           int rhi)
+                                                           int rhi, WgOrder order)
 {
     static_assert(WKP == 32, "row shuffles assume 32 lanes per row");
     constexpr int WK = 2 * WKP;
@@ -51,8 +51,11 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
 
     const int tid = threadIdx.x;
     const int m = tid % WKP, g = tid / WKP;
-    const int chunk = blockIdx.x % nchunks;
-    const int tile = blockIdx.x / nchunks;
+    const int item = order.item(blockIdx.x);
+    if (item < 0) return;  // grid padding; uniform per workgroup
+    const int ntiles = order.total / nchunks;
+    const int chunk = order.blocked ? item / ntiles : item % nchunks;
+    const int tile = order.blocked ? item % ntiles : item / nchunks;
     const int tk = tile % tiles_k, tj = tile / tiles_k;
     const int j0 = tj * TJ - 2, k0 = tk * TK - 2;
     const int nJ = (int)phi.d[1], nK = (int)phi.d[2];
@@ -205,13 +208,14 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
         double t = red[0];
 #pragma unroll
         for (int w = 1; w < NT / 64; w++) t += red[w];
-        partials[blockIdx.x] = t;
+        partials[item] = t;
     }
 }
 
 struct Geometry {
     int tiles_j, tiles_k, nchunks, CI;
-    unsigned grid;
+    WgOrder order;
+    unsigned grid;  // = order.total: workgroups that do work, and partial sums written
 };
 
 // window rows: 32 (256 threads) or 64 (512 threads; fewer halo rows re-read per owned row, pays
@@ -230,7 +234,9 @@ Geometry geometry(const int64_t n[3], IRange r)
     const int64_t planes = r.hi - r.lo;
     g.tiles_j = (int)((n[1] + TJ - 1) / TJ);
     g.tiles_k = (int)((n[2] + TK - 1) / TK);
-    int nchunks = pick_chunks((int64_t)g.tiles_j * g.tiles_k, planes, 3, 2, window_rows(n) == 64 ? 256 : 512);
+    const bool blocked = wg_order_blocked();
+    int nchunks = pick_chunks((int64_t)g.tiles_j * g.tiles_k, planes, 3, 2, window_rows(n) == 64 ? 256 : 512,
+                              !blocked);
     static const int want = [] { const char *e = getenv("MG_RR_CHUNKS"); return e ? atoi(e) : 0; }();
     if (want > 0) nchunks = want;
     int CI = (int)((planes + nchunks - 1) / nchunks);
@@ -238,6 +244,7 @@ Geometry geometry(const int64_t n[3], IRange r)
     g.nchunks = nchunks;
     g.CI = CI;
     g.grid = (unsigned)(nchunks * g.tiles_j * g.tiles_k);
+    g.order = WgOrder{(int)g.grid, blocked ? 1 : 0};
     return g;
 }
 
@@ -255,8 +262,8 @@ void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const 
     static const int threads = [] { const char *e = getenv("MG_RR_NT"); return e ? atoi(e) : 256; }();
     static const int depth = [] { const char *e = getenv("MG_RR_D"); return e ? atoi(e) : 2; }();
 #define LAUNCHW(WJ, D, RF, NT)                                                                        \
-    hipLaunchKernelGGL((k_residual_restrict<WJ, 32, D, RF, NT>), dim3(g.grid), dim3(NT), 0, s, phi, b, \
-                       Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi)
+    hipLaunchKernelGGL((k_residual_restrict<WJ, 32, D, RF, NT>), dim3(g.order.grid()), dim3(NT), 0, s, phi, b, \
+                       Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi, g.order)
 #define LAUNCH(D, RF, NT) LAUNCHW(32, D, RF, NT)
     if (window_rows(n) == 64) {
         if (Rf.p) LAUNCHW(64, 2, true, 512);

@@ -55,7 +55,7 @@ enum : int {
 template <int WJ, int WKP, int D, int NT, int MODE>
 __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, View ec, int nI, int nJ,
                                                   int nK, Coef c, double omega, int CI, int nchunks,
-                                                  int tiles_k, int rlo, int rhi)
+                                                  int tiles_k, int rlo, int rhi, WgOrder order)
 {
     constexpr int WK = 2 * WKP;
     constexpr int TJ = WJ - 4, TK = WK - 4;
@@ -74,10 +74,13 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
     // RPP/2 apart instead of adjacent ones: rows of equal parity have their red point in the same
     // pair element and the same prolongation case, so the wave does not diverge.
     const int rw = (rr >> 1) + (RPP / 2) * (rr & 1);
-    // chunk index fastest: with a multiple of 8 chunks all windows of a chunk share blockIdx % 8,
-    // i.e. one XCD and its L2
-    const int chunk = blockIdx.x % nchunks;
-    const int tile = blockIdx.x / nchunks;
+    // plain order: chunk index fastest (with a multiple of 8 chunks all windows of a chunk share
+    // blockIdx % 8, i.e. one XCD); blocked order: chunk slowest, each XCD a contiguous run of windows
+    const int item = order.item(blockIdx.x);
+    if (item < 0) return;  // grid padding; uniform per workgroup
+    const int ntiles = order.total / nchunks;
+    const int chunk = order.blocked ? item / ntiles : item % nchunks;
+    const int tile = order.blocked ? item % ntiles : item / nchunks;
     const int tk = tile % tiles_k, tj = tile / tiles_k;
     const int j0 = tj * TJ - 2, k0 = tk * TK - 2;
     const int uJ = (int)uin.d[1], uK = (int)uin.d[2];
@@ -322,14 +325,16 @@ static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec
     const int tiles_j = (int)((uin.d[1] + TJ - 1) / TJ);
     const int tiles_k = (int)((uin.d[2] + TK - 1) / TK);
     const int tiles = tiles_j * tiles_k;
-    int nchunks = pick_chunks(tiles, planes, 4, 1, WJ == 32 ? 512 : 256);
+    const bool blocked = wg_order_blocked();
+    int nchunks = pick_chunks(tiles, planes, 4, 1, WJ == 32 ? 512 : 256, !blocked);
     if (want_chunks > 0) nchunks = want_chunks;
     const int CI = (int)((planes + nchunks - 1) / nchunks);
-    const unsigned grid = (unsigned)(nchunks * tiles);
+    const WgOrder order{nchunks * tiles, blocked ? 1 : 0};
+    const unsigned grid = order.grid();
 #define LAUNCH(MODE)                                                                                 \
     hipLaunchKernelGGL((k_sweep_rb<WJ, WKP, D, NT, MODE>), dim3(grid), dim3(NT), 0, s, uin, uout, rhs, \
                        ec, (int)n[0], (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k, (int)r.lo, \
-                       (int)r.hi)
+                       (int)r.hi, order)
     if (load_op == kLoadCorrect) LAUNCH(kLoadCorrect);
     else if (load_op == kLoadProlong) LAUNCH(kLoadProlong);
     else LAUNCH(kLoadPlain);
