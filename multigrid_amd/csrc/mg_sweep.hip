@@ -49,6 +49,47 @@ enum : int {
     kLoadProlong = 2   // u := P(ec) on 0..n-2, 0 at index 0 (reference cpp/PotentialSolver.cpp:3940-3976)
 };
 
+
+// One colour phase of the sweep for the Q points a lane owns in a plane.  E (which element of
+// the lane's pairs has this colour) is a template argument: the caller branches on it once per
+// phase with a wave-uniform condition, so no per-point selects remain.  P points at the lane's
+// (row rw, pair m) element of the plane's LDS slot; in-plane neighbours are constant offsets.
+template <int E> __device__ __forceinline__ double &elem(d2 &v) { return E ? v.y : v.x; }
+template <int E> __device__ __forceinline__ double elem(const d2 &v) { return E ? v.y : v.x; }
+
+template <int E, int Q, int ROWSTEP, int WK>
+__device__ __forceinline__ void red_phase_impl(double *P, d2 (&v0)[Q], const d2 (&vm1)[Q], const d2 (&vp1)[Q],
+                                               const d2 (&b0)[Q], unsigned okmask, const Coef &c, double omega)
+{
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        double *X = P + q * ROWSTEP + E;
+        const double uc = elem<E>(v0[q]);
+        const double g = div_d(elem<E>(b0[q]) + c.cx * (elem<E>(vm1[q]) + elem<E>(vp1[q])) +
+                               c.cy * (X[-WK] + X[WK]) + c.cz * (X[-1] + X[1]), c);
+        const bool ok = (okmask >> (E * Q + q)) & 1u;
+        const double un = ok ? uc + omega * (g - uc) : uc;
+        elem<E>(v0[q]) = un;
+        X[0] = un;
+    }
+}
+
+template <int E, int Q, int ROWSTEP, int WK>
+__device__ __forceinline__ void black_phase_impl(const double *P, d2 (&vm1)[Q], const d2 (&vm2)[Q],
+                                                 const d2 (&v0)[Q], const d2 (&bm1)[Q], unsigned okmask,
+                                                 const Coef &c, double omega)
+{
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const double *Y = P + q * ROWSTEP + E;
+        const double uc = elem<E>(vm1[q]);
+        const double g = div_d(elem<E>(bm1[q]) + c.cx * (elem<E>(vm2[q]) + elem<E>(v0[q])) +
+                               c.cy * (Y[-WK] + Y[WK]) + c.cz * (Y[-1] + Y[1]), c);
+        const bool ok = (okmask >> ((2 + E) * Q + q)) & 1u;
+        elem<E>(vm1[q]) = ok ? uc + omega * (g - uc) : uc;
+    }
+}
+
 // WJ rows x 2*WKP columns per window; outputs are the window minus two rings.
 // D = planes of u (and of the right-hand side) requested ahead of use: the march is
 // latency bound unless several planes per workgroup are in flight.
@@ -65,7 +106,12 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
     constexpr int CKP = CK + 1;                   // padded row
     constexpr int CE = (CJ * CK + NT - 1) / NT;   // coarse elements staged per thread
     static_assert(WJ % RPP == 0, "window rows must be a multiple of rows per pass");
-    __shared__ double lds[3][WJ][WK];
+    static_assert(RPP % 4 == 0 && TJ % 2 == 0, "row parity must be the same for all rows of a wave");
+    // Three plane slots, each with a guard row above and below the window: the in-plane
+    // neighbours of any window point are then plain constant offsets from the point (the values
+    // read across a window edge are garbage that only reaches points which are not updated).
+    constexpr int PL = (WJ + 2) * WK;  // doubles per slot
+    __shared__ double lds[3 * PL];
     __shared__ double cl[2][CJ][CKP];  // staged coarse planes; unused (and not allocated) in plain mode
 
     const int tid = threadIdx.x;
@@ -74,6 +120,8 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
     // RPP/2 apart instead of adjacent ones: rows of equal parity have their red point in the same
     // pair element and the same prolongation case, so the wave does not diverge.
     const int rw = (rr >> 1) + (RPP / 2) * (rr & 1);
+    // offset of (row rw, pair m) inside a slot; row q*RPP + rw is q*RPP*WK further
+    const int tbase = (rw + 1) * WK + 2 * m;
     // plain order: chunk index fastest (with a multiple of 8 chunks all windows of a chunk share
     // blockIdx % 8, i.e. one XCD); blocked order: chunk slowest, each XCD a contiguous run of windows
     const int item = order.item(blockIdx.x);
@@ -211,9 +259,23 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
     }
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        const int r = q * RPP + rw;
-        *reinterpret_cast<d2 *>(&lds[(ia - 1 + 3) % 3][r][2 * m]) = v0[q];
+        *reinterpret_cast<d2 *>(&lds[((ia - 1 + 3) % 3) * PL + tbase + q * RPP * WK]) = v0[q];
     }
+
+    // Which of this lane's points may be updated, per phase (red: window minus one ring, black:
+    // minus two), pair element E and row q: bit (phase*2 + E)*Q + q.  Loop invariant.
+    unsigned okmask = 0;
+#pragma unroll
+    for (int ph = 0; ph < 2; ph++)
+#pragma unroll
+        for (int E = 0; E < 2; E++)
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int r = q * RPP + rw, j = j0 + r, col = 2 * m + E, k = k0 + col;
+                const bool ok = j >= 1 && j <= nJ - 2 && k >= 1 && k <= nK - 2 && r >= 1 + ph && r <= WJ - 2 - ph &&
+                                col >= 1 + ph && col <= WK - 2 - ph;
+                okmask |= (ok ? 1u : 0u) << ((ph * 2 + E) * Q + q);
+            }
 
     for (int p = ia - 1; p <= ib; p++) {
 #pragma unroll
@@ -232,26 +294,13 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
         }
         __syncthreads();
         // ---- red points of plane p (neighbours: old black values) ----------
+        // Every row of this lane has the parity of rw (j0 and RPP are even), and the two halves
+        // of a wave take rows of equal parity: which element of a pair is red is wave-uniform.
+        const bool e1 = __builtin_amdgcn_readfirstlane((p + j0 + rw) & 1) != 0;
         if (p >= 1 && p <= nI - 2) {
-            double(*X)[WK] = lds[(p + 3) % 3];
-#pragma unroll
-            for (int q = 0; q < Q; q++) {
-                const int r = q * RPP + rw;
-                const int j = j0 + r;
-                const int e = (p + j) & 1;
-                const int col = 2 * m + e;
-                const int k = k0 + col;
-                const bool ok = j >= 1 && j <= nJ - 2 && k >= 1 && k <= nK - 2 && r >= 1 &&
-                                r <= WJ - 2 && col >= 1 && col <= WK - 2;
-                const int rn = max(r - 1, 0), rs = min(r + 1, WJ - 1);
-                const int cw = max(col - 1, 0), ce = min(col + 1, WK - 1);
-                const double uc = pick(v0[q], e);
-                const double g = div_d(pick(b0[q], e) + c.cx * (pick(vm1[q], e) + pick(vp1[q], e)) +
-                                       c.cy * (X[rn][col] + X[rs][col]) + c.cz * (X[r][cw] + X[r][ce]), c);
-                const double un = ok ? uc + omega * (g - uc) : uc;
-                v0[q] = put(v0[q], e, un);
-                X[r][col] = un;
-            }
+            double *X = &lds[((p + 3) % 3) * PL + tbase];
+            if (e1) red_phase_impl<1, Q, RPP * WK, WK>(X, v0, vm1, vp1, b0, okmask, c, omega);
+            else red_phase_impl<0, Q, RPP * WK, WK>(X, v0, vm1, vp1, b0, okmask, c, omega);
         }
         if (MODE != kLoadPlain && !(f & 1)) stage_write((f >> 1) + 1, cv);
         __syncthreads();
@@ -259,23 +308,10 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
         const int pb = p - 1;
         if (pb >= ia && pb < ib) {
             if (pb >= 1 && pb <= nI - 2) {
-                double(*Y)[WK] = lds[(pb + 3) % 3];
-#pragma unroll
-                for (int q = 0; q < Q; q++) {
-                    const int r = q * RPP + rw;
-                    const int j = j0 + r;
-                    const int e = (p + j) & 1;  // black of plane p-1 sits where red of plane p does
-                    const int col = 2 * m + e;
-                    const int k = k0 + col;
-                    const bool ok = j >= 1 && j <= nJ - 2 && k >= 1 && k <= nK - 2 && r >= 2 &&
-                                    r <= WJ - 3 && col >= 2 && col <= WK - 3;
-                    const int rn = max(r - 1, 0), rs = min(r + 1, WJ - 1);
-                    const int cw = max(col - 1, 0), ce = min(col + 1, WK - 1);
-                    const double uc = pick(vm1[q], e);
-                    const double g = div_d(pick(bm1[q], e) + c.cx * (pick(vm2[q], e) + pick(v0[q], e)) +
-                                           c.cy * (Y[rn][col] + Y[rs][col]) + c.cz * (Y[r][cw] + Y[r][ce]), c);
-                    vm1[q] = put(vm1[q], e, ok ? uc + omega * (g - uc) : uc);
-                }
+                // black of plane p-1 sits where red of plane p does
+                const double *Y = &lds[((pb + 3) % 3) * PL + tbase];
+                if (e1) black_phase_impl<1, Q, RPP * WK, WK>(Y, vm1, vm2, v0, bm1, okmask, c, omega);
+                else black_phase_impl<0, Q, RPP * WK, WK>(Y, vm1, vm2, v0, bm1, okmask, c, omega);
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) {
@@ -289,7 +325,7 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const int r = q * RPP + rw;
-            *reinterpret_cast<d2 *>(&lds[(p + 1 + 3) % 3][r][2 * m]) = vp1[q];
+            *reinterpret_cast<d2 *>(&lds[((p + 1 + 3) % 3) * PL + tbase + q * RPP * WK]) = vp1[q];
             vm2[q] = vm1[q];
             vm1[q] = v0[q];
             v0[q] = vp1[q];
@@ -351,7 +387,9 @@ static void launch_sweep(hipStream_t s, View uin, View uout, View rhs, View ec, 
     // enough windows to fill the chip.  MG_SWEEP_WJ=32|64 overrides (A/B runs).
     static const int forced = env_int("MG_SWEEP_WJ", 0);
     const int wj = (forced == 32 || forced == 64) ? forced : (uin.d[1] >= 256 ? 64 : 32);
-    if (wj == 64) launch_sweep_t<64, 512>(s, uin, uout, rhs, ec, load_op, n, c, omega, r);
+    static const int nt = env_int("MG_SWEEP_NT", 512);
+    if (wj == 64 && nt == 1024) launch_sweep_t<64, 1024>(s, uin, uout, rhs, ec, load_op, n, c, omega, r);
+    else if (wj == 64) launch_sweep_t<64, 512>(s, uin, uout, rhs, ec, load_op, n, c, omega, r);
     else launch_sweep_t<32, 256>(s, uin, uout, rhs, ec, load_op, n, c, omega, r);
 }
 
