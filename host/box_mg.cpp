@@ -5,7 +5,8 @@
 // synthetic charge density used by this repository's benchmarks.
 //
 //   box_mg [n=41] [depth=2] [tol=1e-4] [--b] [--dump file] [--dump-ef file]
-//   --b selects the reference's "B" solver variant (7-point restriction)
+//   --b selects the reference's "B" solver variant (7-point restriction);
+//   --vti file writes phi, rho and ef as VTK ImageData in the reference's ASCII format
 //   depth 0 selects the plain Gauss-Seidel/SOR solver; --dump writes phi as raw fp64 [i][j][k],
 //   --dump-ef the electric field as raw fp64 [i][j][k][3]
 #include <chrono>
@@ -17,18 +18,20 @@
 #include <iostream>
 
 #include "MultiGridSolverHIP.h"
+#include "Output.h"
 
 int main(int argc, char **argv)
 {
     int n = 41, depth = 2;
     double tol = 1e-4;
-    const char *dump = nullptr, *dump_ef = nullptr;
+    const char *dump = nullptr, *dump_ef = nullptr, *vti = nullptr;
     bool variant_b = false;
     int pos = 0;
     for (int a = 1; a < argc; a++) {
         if (!strcmp(argv[a], "--dump") && a + 1 < argc) dump = argv[++a];
         else if (!strcmp(argv[a], "--dump-ef") && a + 1 < argc) dump_ef = argv[++a];
         else if (!strcmp(argv[a], "--b")) variant_b = true;
+        else if (!strcmp(argv[a], "--vti") && a + 1 < argc) vti = argv[++a];
         else if (pos == 0) { n = atoi(argv[a]); pos++; }
         else if (pos == 1) { depth = atoi(argv[a]); pos++; }
         else if (pos == 2) { tol = atof(argv[a]); pos++; }
@@ -74,6 +77,7 @@ int main(int argc, char **argv)
             }
             fclose(f);
         }
+        if (vti && !Output::fields(world, vti)) return 3;
         delete solver;
         return ok ? 0 : 2;
     } catch (const std::exception &e) {

@@ -69,3 +69,53 @@ def test_gauss_seidel_and_field_through_the_interface(box, gpu, orc, tmp_path):
     lex = np.zeros(N)
     assert orc.gs_solve(lex, orc.synthetic_rho(N), dh, 100000, 1e-6)[0]
     assert rel_l2(phi, lex) <= 1e-6
+
+
+def _parse_vti(path):
+    import re
+    text = open(path).read()
+    head = re.search(r'<ImageData Origin="([^"]*)" Spacing="([^"]*)" WholeExtent="([^"]*)">', text)
+    arrays = {}
+    for name, comps, body in re.findall(
+            r'<DataArray Name="(\w+)" NumberOfComponents="(\d)" format="ascii" type="Float64">\n(.*?)</DataArray>',
+            text, flags=re.S):
+        arrays[name] = (int(comps), [np.array(line.split(), dtype=float) for line in body.strip("\n").split("\n")])
+    return head.groups(), arrays
+
+
+def test_vti_writer_format(tmp_path):
+    """The reference's .vti layout (cpp/Output.cpp:12-65, cpp/Field.h:221-228): ASCII ImageData,
+    one k-plane per line, i fastest within it; vectors as three numbers per node."""
+    exe = os.path.join(ROOT, "host", "vti_selftest")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "vti_selftest"], stdout=subprocess.DEVNULL)
+    out = tmp_path / "t.vti"
+    subprocess.check_call([exe, str(out)])
+    (origin, spacing, extent), arrays = _parse_vti(out)
+    assert origin == "-0.2 -0.2 -0.1" and extent == "0 2 0 3 0 4"
+    assert np.allclose([float(x) for x in spacing.split()], [0.2, 0.1, 0.1])
+    assert open(out).read().startswith('<VTKFile type="ImageData">\n<ImageData Origin=')
+    ni, nj, nk = 3, 4, 5
+    comps, lines = arrays["phi"]
+    assert comps == 1 and len(lines) == nk
+    for k in range(nk):
+        want = [100 * i + 10 * j + k + 0.5 for j in range(nj) for i in range(ni)]
+        assert lines[k].tolist() == want
+    comps, lines = arrays["ef"]
+    assert comps == 3 and len(lines) == nk
+    assert lines[2].reshape(nj, ni, 3)[3, 1].tolist() == [1.0, 3.0, 2.0]
+    assert list(arrays) == ["phi", "rho", "ef"]
+
+
+@pytest.mark.gpu
+def test_driver_writes_vti_of_the_solution(box, gpu, orc, tmp_path):
+    n = 21
+    out, vti = tmp_path / "phi.bin", tmp_path / "f.vti"
+    p = subprocess.run([box, str(n), "2", "1e-6", "--dump", str(out), "--vti", str(vti)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    phi = np.fromfile(out).reshape(n, n, n)
+    _, arrays = _parse_vti(vti)
+    got = np.array(arrays["phi"][1]).reshape(n, n, n)          # [k][j][i]
+    assert np.allclose(got.transpose(2, 1, 0), phi, rtol=1e-5, atol=1e-12)  # 6 significant digits in the file
+    ef = np.array(arrays["ef"][1]).reshape(n, n, n, 3).transpose(2, 1, 0, 3)
+    assert np.allclose(ef, orc.compute_ef(phi, orc.main_extents_dh((n, n, n))), rtol=1e-5, atol=1e-9)
