@@ -19,7 +19,11 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WIDE_LOAD_KERNELS = ("k_sweep_rb", "k_residual_restrict", "k_prolong")  # 16 B/lane global loads
+# FETCH_SIZE tallies a 128-byte read request as 64 bytes on gfx950, so it is doubled before it is
+# compared with a byte count.  Every kernel of this library reads whole lines (coalesced rows): a
+# pass with TCC_EA0_RDREQ_32B/_64B/_128B (tools/profile_rd.sh, summarised by this script when its
+# output is present) shows > 99.99 % of the read requests to be 128-byte ones in all of them.
+FETCH_FACTOR = 2.0
 
 
 def short(name):
@@ -50,9 +54,21 @@ def main(tag):
                 kern[k][f"{which}_bytes_avg"] = sum(v) / len(v)
     for k, d in kern.items():
         if "fetch_bytes_max" in d:
-            wide = k.startswith(WIDE_LOAD_KERNELS)
-            d["fetch_correction"] = 2.0 if wide else None
-            d["hbm_bytes_max_launch"] = (2.0 if wide else 1.0) * d["fetch_bytes_max"] + d.get("write_bytes_max", 0.0)
+            d["fetch_correction"] = FETCH_FACTOR
+            d["hbm_bytes_max_launch"] = FETCH_FACTOR * d["fetch_bytes_max"] + d.get("write_bytes_max", 0.0)
+    # optional: exact read bytes from the request-size counters
+    rd = glob.glob(os.path.join(src, "rd", "*", "*_counter_collection.csv"))
+    if rd:
+        per = defaultdict(lambda: defaultdict(dict))
+        for r in csv.DictReader(open(rd[0])):
+            per[short(r["Kernel_Name"])][r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+        for k, disp in per.items():
+            if k not in kern:
+                continue
+            best = max(disp.values(), key=lambda v: v.get("TCC_EA0_RDREQ_sum", 0.0))
+            n32, n64, n128 = (best.get(f"TCC_EA0_RDREQ_{w}B_sum", 0.0) for w in (32, 64, 128))
+            kern[k]["read_requests_max_launch"] = {"32B": n32, "64B": n64, "128B": n128,
+                                                   "bytes": 32 * n32 + 64 * n64 + 128 * n128}
     bench = json.load(open(os.path.join(src, "bench_stats.json")))
     out = {"tag": tag, "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 "
                                   "--cpu-cycles 0 --no-solve (513^3 V5); --pmc FETCH_SIZE / --pmc WRITE_SIZE in "
@@ -62,14 +78,16 @@ def main(tag):
     json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
     with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
         f.write(f"# rocprofv3 summary `{tag}` — 513^3 V5 cycle, one MI355X\n\n{out['command']}\n\n")
-        f.write("| kernel | calls | avg us | max us | % time | FETCH_SIZE max (MB) | WRITE_SIZE max (MB) | HBM bytes/launch, corrected (MB) |\n|---|---|---|---|---|---|---|---|\n")
+        f.write("| kernel | calls | avg us | max us | % time | FETCH_SIZE max (MB) | WRITE_SIZE max (MB) | "
+                "HBM bytes/launch = 2 x FETCH + WRITE (MB) | read bytes from request sizes (MB) |\n|---|---|---|---|---|---|---|---|---|\n")
         for k, d in sorted(kern.items(), key=lambda kv: -kv[1]["pct"]):
             fm = d.get("fetch_bytes_max")
             wm = d.get("write_bytes_max")
             hb = d.get("hbm_bytes_max_launch")
             f.write(f"| {k} | {d['calls']} | {d['avg_us']:.1f} | {d['max_us']:.1f} | {d['pct']:.1f} | "
                     f"{fm / 1e6 if fm else 0:.1f} | {wm / 1e6 if wm else 0:.1f} | "
-                    f"{hb / 1e6 if hb else 0:.1f}{'' if d.get('fetch_correction') else ' (fetch uncorrected)'} |\n")
+                    f"{hb / 1e6 if hb else 0:.1f} | "
+                    f"{d['read_requests_max_launch']['bytes'] / 1e6 if 'read_requests_max_launch' in d else float('nan'):.1f} |\n")
     print(open(os.path.join(dst, f"{tag}_summary.md")).read())
 
 
