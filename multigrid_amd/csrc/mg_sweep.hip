@@ -173,16 +173,43 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
             if (e < CJ * CK) cl[I & 1][e / CK][e % CK] = v[t];
         }
     };
-    // u as the sweep must see it: the loaded pair of (plane f, window row r) after the on-load
-    // operation.  Reads the staged coarse planes f>>1 and (f>>1)+1.
-    auto fix = [&](d2 raw, int f, int r) -> d2 {
+    // Loop-invariant part of the on-load operation's range tests, one bit per owned row q:
+    // correct: bit q = x may be corrected (j in 1..nJ-2, k in 1..nK-2), bit Q+q = y may;
+    // prolong: bit q / Q+q = x / y lies in the loop range (j <= nJ-2, k <= nK-2),
+    //          bit 2Q+q / 3Q+q = x / y is forced to zero there (j == 0 or k == 0).
+    unsigned fmask = 0;
+    if (MODE != kLoadPlain) {
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int j = j0 + q * RPP + rw;
+            if (MODE == kLoadCorrect) {
+                const bool jin = j >= 1 && j <= nJ - 2;
+                fmask |= (jin && kk >= 1 && kk <= nK - 2 ? 1u : 0u) << q;
+                fmask |= (jin && kk + 1 <= nK - 2 ? 1u : 0u) << (Q + q);
+            } else {
+                const bool jin = j <= nJ - 2;
+                fmask |= (jin && kk <= nK - 2 ? 1u : 0u) << q;
+                fmask |= (jin && kk + 1 <= nK - 2 ? 1u : 0u) << (Q + q);
+                fmask |= (j == 0 || kk == 0 ? 1u : 0u) << (2 * Q + q);
+                fmask |= (j == 0 ? 1u : 0u) << (3 * Q + q);
+            }
+        }
+    }
+    // every row of a wave has the parity of rw (see the colour phases below)
+    const bool oj = __builtin_amdgcn_readfirstlane((j0 + rw) & 1) != 0;
+    // u as the sweep must see it: the loaded pair of (plane f, owned row q) after the on-load
+    // operation.  Reads the staged coarse planes f>>1 and (f>>1)+1.  The interpolation case
+    // (parities of f and j) is wave-uniform: scalar branches.
+    auto fix = [&](d2 raw, int f, int q) -> d2 {
         if constexpr (MODE == kLoadPlain) return raw;
-        const int j = j0 + r;
-        const int I = f >> 1, Jl = r >> 1, Kl = m;
-        const bool oi = f & 1, oj = j & 1;
+        const bool fin = f <= nI - 2 && (MODE != kLoadCorrect || f >= 1);  // plane inside the operation's range
+        const int I = f >> 1, Jl = (q * RPP + rw) >> 1, Kl = m;
         const double(*A)[CKP] = cl[I & 1];
         const double(*B)[CKP] = cl[(I + 1) & 1];
+        const bool oi = f & 1;
         // the eight corner values; the sums below follow the reference's association order
+        // all eight corners are read up front (independent LDS reads in flight together); the case
+        // only decides which of them enter the sums
         const double c000 = A[Jl][Kl], c010 = A[Jl + 1][Kl], c001 = A[Jl][Kl + 1], c011 = A[Jl + 1][Kl + 1];
         const double c100 = B[Jl][Kl], c110 = B[Jl + 1][Kl], c101 = B[Jl][Kl + 1], c111 = B[Jl + 1][Kl + 1];
         double vx, vy;  // interpolant at k = kk (even) and kk+1 (odd)
@@ -203,15 +230,14 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
             vy = 0.125 * ((((s + c001) + c101) + c011) + c111);
         }
         d2 out = raw;
-        const bool fj = f <= nI - 2 && j <= nJ - 2;  // inside the prolongation's loop range
+        const bool mx = fin && ((fmask >> q) & 1u), my = fin && ((fmask >> (Q + q)) & 1u);
         if (MODE == kLoadCorrect) {
-            const bool in = fj && f >= 1 && j >= 1;
-            if (in && kk >= 1 && kk <= nK - 2) out.x = raw.x - vx;
-            if (in && kk + 1 <= nK - 2) out.y = raw.y - vy;
+            if (mx) out.x = raw.x - vx;
+            if (my) out.y = raw.y - vy;
         } else {
-            const bool zero = f == 0 || j == 0;
-            if (fj && kk <= nK - 2) out.x = (zero || kk == 0) ? 0.0 : vx;
-            if (fj && kk + 1 <= nK - 2) out.y = zero ? 0.0 : vy;
+            const bool zx = f == 0 || ((fmask >> (2 * Q + q)) & 1u), zy = f == 0 || ((fmask >> (3 * Q + q)) & 1u);
+            if (mx) out.x = zx ? 0.0 : vx;
+            if (my) out.y = zy ? 0.0 : vy;
         }
         return out;
     };
@@ -249,10 +275,9 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                const int r = q * RPP + rw;
-                if (step == 0) vm1[q] = fix(vm1[q], f, r);
-                else if (step == 1) v0[q] = fix(v0[q], f, r);
-                else vp1[q] = fix(vp1[q], f, r);
+                if (step == 0) vm1[q] = fix(vm1[q], f, q);
+                else if (step == 1) v0[q] = fix(v0[q], f, q);
+                else vp1[q] = fix(vp1[q], f, q);
             }
         }
         // staged now: planes ia>>1 and (ia>>1)+1, which is also what plane ia+1 needs
@@ -278,19 +303,21 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
             }
 
     for (int p = ia - 1; p <= ib; p++) {
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-            vf[D - 1][q] = load_u(min(p + 1 + D, ib + 1), q);
-            bf[D - 1][q] = load_b(min(p + D, ib), q);
-        }
         // plane f = p+2 is fixed at the end of this iteration.  When f is even it needs coarse
         // plane f/2 only (already staged); plane f/2+1, needed from f+1 on, is fetched now and
         // written to the slot plane f/2-1 occupied (last read for f-1, two barriers ago).
+        // These loads are issued BEFORE the plane prefetch below: loads return in order, so the
+        // wait for them (after the red phase) leaves the younger prefetch loads in flight.
         const int f = p + 2;
         double cv[CE];
         if (MODE != kLoadPlain && !(f & 1)) {
 #pragma unroll
             for (int t = 0; t < CE; t++) cv[t] = coarse_elem((f >> 1) + 1, tid + t * NT);
+        }
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            vf[D - 1][q] = load_u(min(p + 1 + D, ib + 1), q);
+            bf[D - 1][q] = load_b(min(p + D, ib), q);
         }
         __syncthreads();
         // ---- red points of plane p (neighbours: old black values) ----------
@@ -324,12 +351,11 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
         // plane p+1 into the LDS slot plane p-2 occupied; plane p+2 arrives and is fixed
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            const int r = q * RPP + rw;
             *reinterpret_cast<d2 *>(&lds[((p + 1 + 3) % 3) * PL + tbase + q * RPP * WK]) = vp1[q];
             vm2[q] = vm1[q];
             vm1[q] = v0[q];
             v0[q] = vp1[q];
-            vp1[q] = fix(vf[0][q], f, r);
+            vp1[q] = fix(vf[0][q], f, q);
             bm1[q] = b0[q];
             b0[q] = bf[0][q];
 #pragma unroll
