@@ -267,6 +267,8 @@ void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const 
 #define LAUNCH(D, RF, NT) LAUNCHW(32, D, RF, NT)
     if (window_rows(n) == 64) {
         if (Rf.p) LAUNCHW(64, 2, true, 512);
+        else if (depth == 3) LAUNCHW(64, 3, false, 512);
+        else if (depth == 1) LAUNCHW(64, 1, false, 512);
         else LAUNCHW(64, 2, false, 512);
     } else if (Rf.p) {
         LAUNCH(2, true, 256);
