@@ -152,31 +152,49 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
                     double(*A)[WK] = ring[(p - 2 + 3) % 3];  // plane 2I-1
                     double(*B)[WK] = ring[(p - 1) % 3];      // plane 2I
                     double(*C)[WK] = ring[p % 3];            // plane 2I+1
-                    for (int t = tid; t < TJC * TKC; t += NT) {
-                        const int Jl = t / TKC, Kl = t % TKC;
+                    // A thread produces up to NOUT coarse points of this plane.  Each is a chain of 26
+                    // dependent additions (the reference's order); the chains of a thread's points are
+                    // advanced together so that they overlap in the pipeline.
+                    constexpr int NOUT = (TJC * TKC + NT - 1) / NT;
+                    int rr_[NOUT], cc_[NOUT];
+                    bool live[NOUT], inject[NOUT];
+                    int64_t at_[NOUT];
+#pragma unroll
+                    for (int o = 0; o < NOUT; o++) {
+                        const int t = tid + o * NT;
+                        const int tc = t < TJC * TKC ? t : 0;  // idle slots recompute point 0, never stored
+                        const int Jl = tc / TKC, Kl = tc % TKC;
                         const int J = tj * TJC + Jl, K = tk * TKC + Kl;
-                        if (J < cJ && K < cK) {
-                            const int r = 2 * Jl + 2, cc = 2 * Kl + 2;
-                            double v;
-                            if (I == 0 || J == 0 || K == 0) {
-                                v = B[r][cc];
-                            } else {
-#define F(di, dj, dk) ((di) < 0 ? A : (di) == 0 ? B : C)[r + (dj)][cc + (dk)]
-                                v = F(-1, -1, -1) + 2 * F(0, -1, -1) + F(1, -1, -1) +
-                                    2 * F(-1, 0, -1) + 4 * F(0, 0, -1) + 2 * F(1, 0, -1) +
-                                    F(-1, 1, -1) + 2 * F(0, 1, -1) + F(1, 1, -1) +
-                                    2 * F(-1, -1, 0) + 4 * F(0, -1, 0) + 2 * F(1, -1, 0) +
-                                    4 * F(-1, 0, 0) + 8 * F(0, 0, 0) + 4 * F(1, 0, 0) +
-                                    2 * F(-1, 1, 0) + 4 * F(0, 1, 0) + 2 * F(1, 1, 0) +
-                                    F(-1, -1, 1) + 2 * F(0, -1, 1) + F(1, -1, 1) +
-                                    2 * F(-1, 0, 1) + 4 * F(0, 0, 1) + 2 * F(1, 0, 1) +
-                                    F(-1, 1, 1) + 2 * F(0, 1, 1) + F(1, 1, 1);
-#undef F
-                                v = v * 0.015625;  // == v / 64.0 exactly (power of two)
-                            }
-                            Rc.p[Rc.at(I, J, K)] = v;
-                        }
+                        live[o] = t < TJC * TKC && J < cJ && K < cK;
+                        inject[o] = I == 0 || J == 0 || K == 0;
+                        rr_[o] = 2 * Jl + 2;
+                        cc_[o] = 2 * Kl + 2;
+                        at_[o] = Rc.at(I, min(J, cJ - 1), min(K, cK - 1));
                     }
+                    double v[NOUT];
+#define F(o, di, dj, dk) ((di) < 0 ? A : (di) == 0 ? B : C)[rr_[o] + (dj)][cc_[o] + (dk)]
+#define TERM1(di, dj, dk) _Pragma("unroll") for (int o = 0; o < NOUT; o++) v[o] = v[o] + F(o, di, dj, dk);
+#define TERMW(w, di, dj, dk) _Pragma("unroll") for (int o = 0; o < NOUT; o++) v[o] = v[o] + (w) * F(o, di, dj, dk);
+#pragma unroll
+                    for (int o = 0; o < NOUT; o++) v[o] = F(o, -1, -1, -1);
+                    TERMW(2, 0, -1, -1) TERM1(1, -1, -1)
+                    TERMW(2, -1, 0, -1) TERMW(4, 0, 0, -1) TERMW(2, 1, 0, -1)
+                    TERM1(-1, 1, -1) TERMW(2, 0, 1, -1) TERM1(1, 1, -1)
+                    TERMW(2, -1, -1, 0) TERMW(4, 0, -1, 0) TERMW(2, 1, -1, 0)
+                    TERMW(4, -1, 0, 0) TERMW(8, 0, 0, 0) TERMW(4, 1, 0, 0)
+                    TERMW(2, -1, 1, 0) TERMW(4, 0, 1, 0) TERMW(2, 1, 1, 0)
+                    TERM1(-1, -1, 1) TERMW(2, 0, -1, 1) TERM1(1, -1, 1)
+                    TERMW(2, -1, 0, 1) TERMW(4, 0, 0, 1) TERMW(2, 1, 0, 1)
+                    TERM1(-1, 1, 1) TERMW(2, 0, 1, 1) TERM1(1, 1, 1)
+#pragma unroll
+                    for (int o = 0; o < NOUT; o++) {
+                        const double full = v[o] * 0.015625;  // == v / 64.0 exactly (power of two)
+                        const double out = inject[o] ? B[rr_[o]][cc_[o]] : full;
+                        if (live[o]) Rc.p[at_[o]] = out;
+                    }
+#undef F
+#undef TERM1
+#undef TERMW
                 }
                 __syncthreads();  // ring slot (p-2)%3 is overwritten by plane p+1 next
             }
