@@ -265,10 +265,13 @@ int mg_dev_sweep_out_of_place(const mg_dev_array *u);
  * The sweep may be out of place: alt has u's shape; *result_in_alt = 1 when the result
  * landed in alt (the caller swaps its references).  Out-of-place sweeps read planes
  * [lo-2, hi+2) of u as far as they exist, so with halos two planes wide one sweep needs
- * one halo exchange.  sweeps > 1 is meant for arrays held whole on one GPU. */
+ * one halo exchange.  sweeps > 1 is meant for arrays held whole on one GPU.
+ * [lo2,hi2) (empty when lo2 == hi2) is a second range, as long as the first and above it, swept
+ * in the same launch -- the planes next to the other slab neighbour; it needs sweeps == 1 and
+ * the out-of-place kernel (mg_dev_sweep_out_of_place). */
 int mg_dev_smooth_rb(void *stream, const mg_dev_array *u, const mg_dev_array *alt,
                      const mg_dev_array *rhs, const int64_t n[3], const double c[4], double omega,
-                     int sweeps, int64_t lo, int64_t hi, int *result_in_alt);
+                     int sweeps, int64_t lo, int64_t hi, int64_t lo2, int64_t hi2, int *result_in_alt);
 /* Coarse planes [lo/2, (hi+1)/2) of Rc = restrict27(residual(phi, b)) for fine planes
  * [lo,hi) (lo even; hi even unless it is the last plane of the level), per-workgroup partial sums of the squared fine
  * residual into partials (capacity `capacity` doubles); *count = partials written.
@@ -293,11 +296,17 @@ int mg_dev_prolong(void *stream, const mg_dev_array *ec, const mg_dev_array *out
  * [lo-2, hi+2) of u as far as they are stored -- folded into the first sweep's loads where
  * the single-pass kernel runs (halo planes of u are then left as they were: the caller
  * exchanges halos after a sweep anyway), as separate launches otherwise.  ec must hold the
- * coarse planes those fine planes interpolate from.  sweeps >= 1. */
+ * coarse planes those fine planes interpolate from.  sweeps >= 1.  [lo2,hi2): second range as
+ * in mg_dev_smooth_rb. */
 int mg_dev_prolong_smooth_rb(void *stream, const mg_dev_array *ec, int correct, const mg_dev_array *u,
                              const mg_dev_array *alt, const mg_dev_array *rhs, const int64_t n[3],
                              const double c[4], double omega, int sweeps, int64_t lo, int64_t hi,
-                             int *result_in_alt);
+                             int64_t lo2, int64_t hi2, int *result_in_alt);
+/* 1 when mg_dev_prolong_smooth_rb folds the operation into the first sweep's loads for an array
+ * of this shape (u itself is then left untouched, and a level may be swept range by range with
+ * overlapping read neighbourhoods); 0 when it applies the operation to u in place first.  The
+ * ptr member is not read. */
+int mg_dev_onload_folds(const mg_dev_array *u, int correct);
 /* Planes [lo,hi) of E = -grad(phi) (cpp/PotentialSolver.cpp:418-458).  ef is a dense device
  * array [plane][nj][nk][3] whose plane 0 is global plane ef_i0 (no row padding).  Reads phi
  * planes [lo-1, hi+1), plus plane 2 when lo == 0 and plane n-3 when hi == n. */

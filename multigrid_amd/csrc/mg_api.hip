@@ -1018,9 +1018,27 @@ int mg_dev_sweep_out_of_place(const mg_dev_array *u)
     return mgk::sweep_is_out_of_place(vu) ? 1 : 0;
 }
 
+int mg_dev_onload_folds(const mg_dev_array *u, int correct)
+{
+    View vu;
+    if (dev_view(u, &vu, "mg_dev_onload_folds", true)) return 0;
+    return mgk::onload_folds(vu, correct != 0) ? 1 : 0;
+}
+
+namespace {
+// second plane range of a sweep call: empty, or as long as the first and above it
+int check_second_range(const View &vu, int64_t lo, int64_t hi, int64_t lo2, int64_t hi2, int sweeps, const char *what)
+{
+    if (lo2 == hi2) return MG_OK;
+    if (lo2 > hi2 || hi2 - lo2 != hi - lo || lo2 < hi || hi2 > vu.i_end() || sweeps != 1)
+        return fail(MG_ERR_INVALID, "%s: the second plane range must be as long as the first, above it, stored, and sweeps must be 1", what);
+    return MG_OK;
+}
+}  // namespace
+
 int mg_dev_smooth_rb(void *stream, const mg_dev_array *u, const mg_dev_array *alt, const mg_dev_array *rhs,
                      const int64_t n[3], const double c[4], double omega, int sweeps, int64_t lo, int64_t hi,
-                     int *result_in_alt)
+                     int64_t lo2, int64_t hi2, int *result_in_alt)
 {
     if (!n || !c || !result_in_alt || sweeps < 0) return fail(MG_ERR_INVALID, "bad argument");
     View vu, va, vr;
@@ -1030,14 +1048,20 @@ int mg_dev_smooth_rb(void *stream, const mg_dev_array *u, const mg_dev_array *al
     if (va.d[0] != vu.d[0] || va.d[1] != vu.d[1] || va.d[2] != vu.d[2] || va.i0 != vu.i0)
         return fail(MG_ERR_INVALID, "mg_dev_smooth_rb: alt must have the shape of u");
     if (lo < vu.i0 || hi > vu.i_end() || lo > hi) return fail(MG_ERR_INVALID, "mg_dev_smooth_rb: bad plane range");
-    const int64_t ulo = lo < 1 ? 1 : lo, uhi = hi > n[0] - 1 ? n[0] - 1 : hi;  // planes actually updated
-    if (ulo < uhi) {
-        // red update of planes ulo-1..uhi reads planes ulo-2..uhi+1 of u; rhs is read on updated planes
-        TRY(need_planes(vu, ulo - 2, uhi + 2, n[0], "mg_dev_smooth_rb(u)"));
-        TRY(need_planes(vr, ulo - 1, uhi + 1, n[0] - 1, "mg_dev_smooth_rb(rhs)"));
+    TRY(check_second_range(vu, lo, hi, lo2, hi2, sweeps, "mg_dev_smooth_rb"));
+    for (int part = 0; part < (lo2 < hi2 ? 2 : 1); part++) {
+        const int64_t a = part ? lo2 : lo, b = part ? hi2 : hi;
+        const int64_t ulo = a < 1 ? 1 : a, uhi = b > n[0] - 1 ? n[0] - 1 : b;  // planes actually updated
+        if (ulo < uhi) {
+            // red update of planes ulo-1..uhi reads planes ulo-2..uhi+1 of u; rhs is read on updated planes
+            TRY(need_planes(vu, ulo - 2, uhi + 2, n[0], "mg_dev_smooth_rb(u)"));
+            TRY(need_planes(vr, ulo - 1, uhi + 1, n[0] - 1, "mg_dev_smooth_rb(rhs)"));
+        }
     }
     const double *before = vu.p;
-    mgk::smooth_rb((hipStream_t)stream, &vu, &va, vr, n, coef4(c), omega, sweeps, IRange{lo, hi});
+    if (mgk::smooth_rb((hipStream_t)stream, &vu, &va, vr, n, coef4(c), omega, sweeps, IRange{lo, hi},
+                       IRange{lo2, hi2}) < 0)
+        return fail(MG_ERR_INVALID, "mg_dev_smooth_rb: a second plane range needs the out-of-place sweep kernel");
     HIP_TRY(hipGetLastError());
     *result_in_alt = vu.p != before;
     return MG_OK;
@@ -1116,7 +1140,7 @@ int mg_dev_prolong(void *stream, const mg_dev_array *ec, const mg_dev_array *out
 int mg_dev_prolong_smooth_rb(void *stream, const mg_dev_array *ec, int correct, const mg_dev_array *u,
                              const mg_dev_array *alt, const mg_dev_array *rhs, const int64_t n[3],
                              const double c[4], double omega, int sweeps, int64_t lo, int64_t hi,
-                             int *result_in_alt)
+                             int64_t lo2, int64_t hi2, int *result_in_alt)
 {
     if (!n || !c || !result_in_alt || sweeps < 1) return fail(MG_ERR_INVALID, "bad argument");
     View vc, vu, va, vr;
@@ -1129,20 +1153,23 @@ int mg_dev_prolong_smooth_rb(void *stream, const mg_dev_array *ec, int correct, 
     if (lo < vu.i0 || hi > vu.i_end() || lo > hi) return fail(MG_ERR_INVALID, "mg_dev_prolong_smooth_rb: bad plane range");
     if (vc.d[1] < (n[1] >> 1) + 1 || vc.d[2] < (n[2] >> 1) + 1)
         return fail(MG_ERR_INVALID, "mg_dev_prolong_smooth_rb: coarse array smaller than (n>>1)+1");
-    const int64_t ulo = lo < 1 ? 1 : lo, uhi = hi > n[0] - 1 ? n[0] - 1 : hi;
-    if (ulo < uhi) {
-        TRY(need_planes(vu, ulo - 2, uhi + 2, n[0], "mg_dev_prolong_smooth_rb(u)"));
-        TRY(need_planes(vr, ulo - 1, uhi + 1, n[0] - 1, "mg_dev_prolong_smooth_rb(rhs)"));
-    }
-    {
+    TRY(check_second_range(vu, lo, hi, lo2, hi2, sweeps, "mg_dev_prolong_smooth_rb"));
+    for (int part = 0; part < (lo2 < hi2 ? 2 : 1); part++) {
+        const int64_t a = part ? lo2 : lo, b = part ? hi2 : hi;
+        const int64_t ulo = a < 1 ? 1 : a, uhi = b > n[0] - 1 ? n[0] - 1 : b;
+        if (ulo < uhi) {
+            TRY(need_planes(vu, ulo - 2, uhi + 2, n[0], "mg_dev_prolong_smooth_rb(u)"));
+            TRY(need_planes(vr, ulo - 1, uhi + 1, n[0] - 1, "mg_dev_prolong_smooth_rb(rhs)"));
+        }
         // fine planes the operation is applied to, and the coarse planes they interpolate from
-        int64_t flo = lo - 2 < vu.i0 ? vu.i0 : lo - 2, fhi = hi + 2 > vu.i_end() ? vu.i_end() : hi + 2;
+        int64_t flo = a - 2 < vu.i0 ? vu.i0 : a - 2, fhi = b + 2 > vu.i_end() ? vu.i_end() : b + 2;
         if (fhi > n[0] - 1) fhi = n[0] - 1;
         if (flo < fhi) TRY(need_planes(vc, flo >> 1, ((fhi - 1) >> 1) + 2, (n[0] >> 1) + 1, "mg_dev_prolong_smooth_rb(ec)"));
     }
     const double *before = vu.p;
-    mgk::prolong_smooth_rb((hipStream_t)stream, vc, correct != 0, &vu, &va, vr, n, coef4(c), omega, sweeps,
-                           IRange{lo, hi});
+    if (mgk::prolong_smooth_rb((hipStream_t)stream, vc, correct != 0, &vu, &va, vr, n, coef4(c), omega, sweeps,
+                               IRange{lo, hi}, IRange{lo2, hi2}) < 0)
+        return fail(MG_ERR_INVALID, "mg_dev_prolong_smooth_rb: a second plane range needs the out-of-place sweep kernel");
     HIP_TRY(hipGetLastError());
     *result_in_alt = vu.p != before;
     return MG_OK;

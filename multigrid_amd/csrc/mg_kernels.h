@@ -145,24 +145,30 @@ void smooth_colour(hipStream_t s, View u, View rhs, const int64_t n[3], Coef c, 
 // One full red-black sweep (both colours) in a single pass, out of place: planes r of
 // u_out = sweep(u_in); points outside 1..n-2 are copied through.  u_in must hold planes
 // [r.lo-2, r.hi+2) as far as they exist in the global array (gI planes).
+// A non-empty r2 (same length as r, disjoint, above it) is swept in the same launch.
 void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c,
-                    double omega, IRange r);
+                    double omega, IRange r, IRange r2 = IRange{0, 0});
 // The same with the operation that precedes the sweep applied to u_in as it is loaded:
 // correct: u_in := u_in - P(ec) (fine grid, phi -= eps_h); otherwise u_in := P(ec) over
 // 0..n-2 (a coarse level's prolongated initial guess).  ec = eps of the next coarser level.
 void sweep_rb_fused_onload(hipStream_t s, View uin, View uout, View rhs, View ec, bool correct,
-                           const int64_t n[3], Coef c, double omega, IRange r);
+                           const int64_t n[3], Coef c, double omega, IRange r, IRange r2 = IRange{0, 0});
 // True when smooth_rb on an array of this shape (with a twin to write to) runs the out-of-place
 // single-pass kernel: disjoint plane ranges of one sweep are then independent launches.
 bool sweep_is_out_of_place(const View &u);
+// True when prolong_smooth_rb folds the prolongation (correct: the correction) into the loads of
+// the first sweep and leaves u itself untouched; otherwise it applies it in place to the planes
+// around the range, and a caller that sweeps a level range by range must not let those overlap.
+bool onload_folds(const View &u, bool correct);
 // `sweeps` red-black sweeps preceded by the prolongation from ec (correct: by phi -= P(ec)):
 // fused into the first sweep where the single-pass kernel is used, separate launches otherwise.
 int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, View rhs,
-                      const int64_t n[3], Coef c, double omega, int sweeps, IRange r);
+                      const int64_t n[3], Coef c, double omega, int sweeps, IRange r, IRange r2 = IRange{0, 0});
 // `sweeps` red-black sweeps on planes r of *u.  May ping-pong between *u and *alt (same
 // shape); on return *u is the view holding the result.  Returns the kernels launched.
+// r2: second plane range for the same (single, out-of-place) sweep; see sweep_rb_fused.
 int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c, double omega,
-              int sweeps, IRange r);
+              int sweeps, IRange r, IRange r2 = IRange{0, 0});
 
 // R = A*phi - b inside, R = phi on the faces of the n-sized level, for planes r; per-workgroup
 // sums of squares go to partials[0..residual_partials(n, r)).

@@ -403,10 +403,14 @@ bool wg_order_blocked()
 bool sweep_is_out_of_place(const View &u) { return use_fused_sweep(u); }
 
 int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c,
-              double omega, int sweeps, IRange r)
+              double omega, int sweeps, IRange r, IRange r2)
 {
     if (n[0] < 3 || n[1] < 3 || n[2] < 3) return 0;
-    const bool whole = u->i0 == 0 && r.lo == 0 && r.hi == u->d[0] && rhs.i0 == 0;
+    const bool pair = r2.hi > r2.lo;
+    if (pair && !(sweeps == 1 && alt && alt->p && use_fused_sweep(*u) && r2.hi - r2.lo == r.hi - r.lo &&
+                  r2.lo >= r.hi))
+        return -1;  // a second range needs the out-of-place kernel and one sweep
+    const bool whole = !pair && u->i0 == 0 && r.lo == 0 && r.hi == u->d[0] && rhs.i0 == 0;
     // small enough for one workgroup: all sweeps in a single launch, u in LDS, <= 4 points per
     // colour per thread in registers
     const size_t lds_bytes = sizeof(double) * (size_t)(u->d[0] * u->d[1] * u->d[2]);
@@ -431,7 +435,7 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
     const bool fused = alt && alt->p && use_fused_sweep(*u);
     for (int sw = 0; sw < sweeps; sw++) {
         if (fused) {
-            sweep_rb_fused(s, *u, *alt, rhs, n, c, omega, r);
+            sweep_rb_fused(s, *u, *alt, rhs, n, c, omega, r, r2);
             View t = *u;
             *u = *alt;
             *alt = t;
@@ -451,15 +455,24 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
     return fused ? sweeps : 2 * sweeps;
 }
 
-int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, View rhs,
-                      const int64_t n[3], Coef c, double omega, int sweeps, IRange r)
+bool onload_folds(const View &u, bool correct)
 {
     static const bool allow = getenv("MG_NO_ONLOAD") == nullptr;  // A/B: force separate launches
     // On-load prolongation pays on big levels only (measured at 129^3: 35 us fused against
     // 23 + 5 us separate; at 257^3: 125 against 107 + 27); the fine-grid correction always pays.
-    const bool big = correct || (u->d[1] >= 256 && u->d[2] >= 256);
-    if (allow && big && sweeps > 0 && alt && alt->p && use_fused_sweep(*u)) {
-        sweep_rb_fused_onload(s, *u, *alt, rhs, ec, correct, n, c, omega, r);
+    const bool big = correct || (u.d[1] >= 256 && u.d[2] >= 256);
+    return allow && big && use_fused_sweep(u);
+}
+
+int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, View rhs,
+                      const int64_t n[3], Coef c, double omega, int sweeps, IRange r, IRange r2)
+{
+    const bool pair = r2.hi > r2.lo;
+    if (pair && !(sweeps == 1 && alt && alt->p && use_fused_sweep(*u) && r2.hi - r2.lo == r.hi - r.lo &&
+                  r2.lo >= r.hi))
+        return -1;
+    if (sweeps > 0 && alt && alt->p && onload_folds(*u, correct)) {
+        sweep_rb_fused_onload(s, *u, *alt, rhs, ec, correct, n, c, omega, r, r2);
         View t = *u;
         *u = *alt;
         *alt = t;
@@ -468,13 +481,19 @@ int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, 
     // separate launches: the operation must reach every stored plane the first sweep reads
     // (planes r.lo-2 .. r.hi+1; in a slab those are halo planes, whose coarse neighbours the
     // caller keeps current)
-    IRange pr{r.lo - 2, r.hi + 2};
-    if (pr.lo < u->i0) pr.lo = u->i0;
-    if (pr.hi > u->i_end()) pr.hi = u->i_end();
-    if (pr.hi > n[0]) pr.hi = n[0];
-    if (correct) prolong_correct(s, ec, *u, n, pr);
-    else prolong(s, ec, *u, n, pr);
-    return 1 + smooth_rb(s, u, alt, rhs, n, c, omega, sweeps, r);
+    int launches = 0;
+    for (int part = 0; part < (pair ? 2 : 1); part++) {
+        const IRange q = part ? r2 : r;
+        IRange pr{q.lo - 2, q.hi + 2};
+        if (part && pr.lo < r.hi + 2) pr.lo = r.hi + 2;  // planes the first part already covered
+        if (pr.lo < u->i0) pr.lo = u->i0;
+        if (pr.hi > u->i_end()) pr.hi = u->i_end();
+        if (pr.hi > n[0]) pr.hi = n[0];
+        if (correct) prolong_correct(s, ec, *u, n, pr);
+        else prolong(s, ec, *u, n, pr);
+        launches++;
+    }
+    return launches + smooth_rb(s, u, alt, rhs, n, c, omega, sweeps, r, r2);
 }
 
 void residual(hipStream_t s, View phi, View b, View R, const int64_t n[3], Coef c, double *partials,

@@ -96,7 +96,7 @@ __device__ __forceinline__ void black_phase_impl(const double *P, d2 (&vm1)[Q], 
 template <int WJ, int WKP, int D, int NT, int MODE>
 __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, View ec, int nI, int nJ,
                                                   int nK, Coef c, double omega, int CI, int nchunks,
-                                                  int tiles_k, int rlo, int rhi, WgOrder order)
+                                                  int tiles_k, int rlo, int rhi, WgOrder order, int cstride)
 {
     constexpr int WK = 2 * WKP;
     constexpr int TJ = WJ - 4, TK = WK - 4;
@@ -136,7 +136,8 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
     // stored plane ranges of the (possibly slab) views, global indices
     const int ulo = (int)uin.i0, uhi = (int)uin.i_end() - 1;
     const int blo = (int)rhs.i0, bhi = (int)rhs.i_end() - 1;
-    const int ia = rlo + chunk * CI;
+    // chunks are CI planes long and start cstride planes apart (cstride == CI: one contiguous range)
+    const int ia = rlo + chunk * cstride;
     const int ib = min(ia + CI, rhi);
     if (ia >= ib) return;  // uniform per workgroup
     const int kk = k0 + 2 * m;  // first column of this lane's pairs
@@ -377,7 +378,7 @@ static int env_int(const char *name, int dflt)
 
 template <int WJ, int NT>
 static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec, int load_op,
-                           const int64_t n[3], Coef c, double omega, IRange r)
+                           const int64_t n[3], Coef c, double omega, IRange r, IRange r2)
 {
     constexpr int WKP = 32, D = 2;
     constexpr int TJ = WJ - 4, TK = 2 * WKP - 4;
@@ -390,13 +391,22 @@ static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec
     const bool blocked = wg_order_blocked();
     int nchunks = pick_chunks(tiles, planes, 4, 1, WJ == 32 ? 512 : 256, !blocked);
     if (want_chunks > 0) nchunks = want_chunks;
-    const int CI = (int)((planes + nchunks - 1) / nchunks);
+    int CI = (int)((planes + nchunks - 1) / nchunks);
+    int cstride = CI, rhi = (int)r.hi;
+    if (r2.hi > r2.lo) {
+        // two short ranges of equal length in one launch (the planes next to either slab
+        // neighbour): one chunk each
+        nchunks = 2;
+        CI = (int)planes;
+        cstride = (int)(r2.lo - r.lo);
+        rhi = (int)r2.hi;
+    }
     const WgOrder order{nchunks * tiles, blocked ? 1 : 0};
     const unsigned grid = order.grid();
 #define LAUNCH(MODE)                                                                                 \
     hipLaunchKernelGGL((k_sweep_rb<WJ, WKP, D, NT, MODE>), dim3(grid), dim3(NT), 0, s, uin, uout, rhs, \
                        ec, (int)n[0], (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k, (int)r.lo, \
-                       (int)r.hi, order)
+                       rhi, order, cstride)
     if (load_op == kLoadCorrect) LAUNCH(kLoadCorrect);
     else if (load_op == kLoadProlong) LAUNCH(kLoadProlong);
     else LAUNCH(kLoadPlain);
@@ -407,28 +417,28 @@ static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec
 // (n = level size); every other element of those planes is copied through unchanged.
 // load_op (kLoad*) is applied to u_in on the fly with the coarse array ec.
 static void launch_sweep(hipStream_t s, View uin, View uout, View rhs, View ec, int load_op,
-                         const int64_t n[3], Coef c, double omega, IRange r)
+                         const int64_t n[3], Coef c, double omega, IRange r, IRange r2)
 {
     // 64-row windows (512 threads) re-read fewer halo rows per owned row; they pay once a plane has
     // enough windows to fill the chip.  MG_SWEEP_WJ=32|64 overrides (A/B runs).
     static const int forced = env_int("MG_SWEEP_WJ", 0);
     const int wj = (forced == 32 || forced == 64) ? forced : (uin.d[1] >= 256 ? 64 : 32);
     static const int nt = env_int("MG_SWEEP_NT", 512);
-    if (wj == 64 && nt == 1024) launch_sweep_t<64, 1024>(s, uin, uout, rhs, ec, load_op, n, c, omega, r);
-    else if (wj == 64) launch_sweep_t<64, 512>(s, uin, uout, rhs, ec, load_op, n, c, omega, r);
-    else launch_sweep_t<32, 256>(s, uin, uout, rhs, ec, load_op, n, c, omega, r);
+    if (wj == 64 && nt == 1024) launch_sweep_t<64, 1024>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
+    else if (wj == 64) launch_sweep_t<64, 512>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
+    else launch_sweep_t<32, 256>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
 }
 
 void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c,
-                    double omega, IRange r)
+                    double omega, IRange r, IRange r2)
 {
-    launch_sweep(s, uin, uout, rhs, uin, kLoadPlain, n, c, omega, r);
+    launch_sweep(s, uin, uout, rhs, uin, kLoadPlain, n, c, omega, r, r2);
 }
 
 void sweep_rb_fused_onload(hipStream_t s, View uin, View uout, View rhs, View ec, bool correct,
-                           const int64_t n[3], Coef c, double omega, IRange r)
+                           const int64_t n[3], Coef c, double omega, IRange r, IRange r2)
 {
-    launch_sweep(s, uin, uout, rhs, ec, correct ? kLoadCorrect : kLoadProlong, n, c, omega, r);
+    launch_sweep(s, uin, uout, rhs, ec, correct ? kLoadCorrect : kLoadProlong, n, c, omega, r, r2);
 }
 
 }  // namespace mgk

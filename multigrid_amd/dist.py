@@ -161,21 +161,29 @@ class HipOps:
     def div_eps0(self, v):
         self._check(self.lib.mg_dev_div_eps0(self._stream(), C.byref(self._arr(v))))
 
-    def smooth(self, u, alt, rhs, n, c, omega, sweeps, lo, hi):
-        """Returns True when the result landed in `alt`."""
+    def onload_folds(self, u, correct):
+        """True when prolong_smooth leaves u untouched (the operation rides on the sweep's loads)."""
+        return bool(self.lib.mg_dev_onload_folds(C.byref(self._arr(u)), int(correct)))
+
+    def smooth(self, u, alt, rhs, n, c, omega, sweeps, lo, hi, second=None):
+        """Returns True when the result landed in `alt`.  second = (lo2, hi2): another range of
+        the same length swept in the same launch (out-of-place kernel, one sweep)."""
         flag = C.c_int(0)
+        lo2, hi2 = second or (0, 0)
         self._check(self.lib.mg_dev_smooth_rb(self._stream(), C.byref(self._arr(u)), C.byref(self._arr(alt)),
                                               C.byref(self._arr(rhs)), (C.c_int64 * 3)(*n), (C.c_double * 4)(*c),
-                                              omega, sweeps, lo, hi, C.byref(flag)))
+                                              omega, sweeps, lo, hi, lo2, hi2, C.byref(flag)))
         return bool(flag.value)
 
-    def prolong_smooth(self, ec, correct, u, alt, rhs, n, c, omega, lo, hi):
-        """One sweep of planes [lo,hi) preceded by u := P(ec) (or u -= P(ec) when correct) on the
-        stored planes the sweep reads.  Returns True when the result landed in `alt`."""
+    def prolong_smooth(self, ec, correct, u, alt, rhs, n, c, omega, lo, hi, second=None):
+        """One sweep of planes [lo,hi) (and `second`) preceded by u := P(ec) (or u -= P(ec) when
+        correct) on the stored planes the sweep reads.  Returns True when the result landed in `alt`."""
         flag = C.c_int(0)
+        lo2, hi2 = second or (0, 0)
         self._check(self.lib.mg_dev_prolong_smooth_rb(
             self._stream(), C.byref(self._arr(ec)), int(correct), C.byref(self._arr(u)), C.byref(self._arr(alt)),
-            C.byref(self._arr(rhs)), (C.c_int64 * 3)(*n), (C.c_double * 4)(*c), omega, 1, lo, hi, C.byref(flag)))
+            C.byref(self._arr(rhs)), (C.c_int64 * 3)(*n), (C.c_double * 4)(*c), omega, 1, lo, hi, lo2, hi2,
+            C.byref(flag)))
         return bool(flag.value)
 
     def residual_restrict(self, phi, b, Rc, n, c, parts, before_part=None):
@@ -422,20 +430,31 @@ class DistSolver:
             else:
                 u, alt, rhs, own = self.eps[l], self.eps_alt[l], self.R[l], self.own(l, "eps")
 
-            def run(lo, hi):
-                if sweep == 0 and ec is not None:
-                    return self.ops.prolong_smooth(ec, correct, u, alt, rhs, n, self.coef[l], self.omega, lo, hi)
-                return self.ops.smooth(u, alt, rhs, n, self.coef[l], self.omega, 1, lo, hi)
-
+            fold = None
             if sweep == 0 and ec is not None:
                 ec.ready()
+                if self.ops.onload_folds(u, correct):
+                    fold = ec  # the operation rides on this sweep's loads; u stays as it is
+                else:
+                    # applied in place once, on every stored plane this sweep reads
+                    u.ready()
+                    plo, phi_ = max(own[0] - self.H_U, u.i0), min(own[1] + self.H_U, u.i0 + u.planes)
+                    self.ops.prolong(ec, u, n, plo, phi_, correct)
+
+            def run(lo, hi, second=None):
+                if fold is not None:
+                    return self.ops.prolong_smooth(fold, correct, u, alt, rhs, n, self.coef[l], self.omega,
+                                                   lo, hi, second)
+                return self.ops.smooth(u, alt, rhs, n, self.coef[l], self.omega, 1, lo, hi, second)
+
             edges, inner = self._split(own, first, last)
             overlap = (self.world > 1 and self.overlap and self.ops.out_of_place(u)
                        and inner[1] - inner[0] >= 2 * self.H_U)
             if overlap:
-                # edge planes need the halos of the previous sweep; the interior does not
+                # edge planes need the halos of the previous sweep; the interior does not.  Both
+                # edges (equally long) go in one launch.
                 u.ready()
-                swapped = [run(lo, hi) for lo, hi in edges]
+                swapped = [run(*edges[0], edges[1] if len(edges) == 2 else None)]
                 self.comm.exchange_start(alt, own, self.H_U)
                 swapped.append(run(*inner))
                 assert all(swapped), "out-of-place sweep expected"

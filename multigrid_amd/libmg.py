@@ -91,7 +91,7 @@ SYMBOLS = {
     "mg_dev_sweep_out_of_place": (C.c_int, [C.POINTER(MgDevArray)]),
     "mg_dev_smooth_rb": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.POINTER(MgDevArray), C.POINTER(MgDevArray),
                                    _i64x3, C.c_double * 4, C.c_double, C.c_int, C.c_int64, C.c_int64,
-                                   C.POINTER(C.c_int)]),
+                                   C.c_int64, C.c_int64, C.POINTER(C.c_int)]),
     "mg_dev_residual_restrict": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.POINTER(MgDevArray),
                                            C.POINTER(MgDevArray), _i64x3, C.c_double * 4, C.c_void_p, C.c_int64,
                                            C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
@@ -102,7 +102,9 @@ SYMBOLS = {
                                  C.c_int64, C.c_int]),
     "mg_dev_prolong_smooth_rb": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.c_int, C.POINTER(MgDevArray),
                                            C.POINTER(MgDevArray), C.POINTER(MgDevArray), _i64x3, C.c_double * 4,
-                                           C.c_double, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_int)]),
+                                           C.c_double, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                           C.POINTER(C.c_int)]),
+    "mg_dev_onload_folds": (C.c_int, [C.POINTER(MgDevArray), C.c_int]),
     "mg_dev_compute_ef": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.c_void_p, C.c_int64, _i64x3, _f64x3,
                                     C.c_int64, C.c_int64]),
 }

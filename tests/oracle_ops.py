@@ -21,6 +21,9 @@ class OracleOps:
     def out_of_place(self, u):
         return self._oop
 
+    def onload_folds(self, u, correct):
+        return self._oop
+
     def zeros(self, shape):
         return torch.zeros(shape, dtype=torch.float64)
 
@@ -37,7 +40,10 @@ class OracleOps:
     def div_eps0(self, v):
         orc.lib().orc_slab_div_eps0(C.byref(self._v(v)))
 
-    def smooth(self, u, alt, rhs, n, c, omega, sweeps, lo, hi):
+    def smooth(self, u, alt, rhs, n, c, omega, sweeps, lo, hi, second=None):
+        if second:
+            assert self._oop and sweeps == 1 and second[1] - second[0] == hi - lo and second[0] >= hi
+            self.smooth(u, alt, rhs, n, c, omega, 1, second[0], second[1])
         if self._oop and sweeps == 1:
             # planes [lo,hi) of alt = one sweep of u: run the in-place slab form on a scratch copy of
             # the planes it touches, keep only the requested planes
@@ -54,7 +60,10 @@ class OracleOps:
                                          (C.c_double * 4)(*c), omega, lo, hi)
         return False  # in place
 
-    def prolong_smooth(self, ec, correct, u, alt, rhs, n, c, omega, lo, hi):
+    def prolong_smooth(self, ec, correct, u, alt, rhs, n, c, omega, lo, hi, second=None):
+        if second:
+            assert self._oop
+            self.prolong_smooth(ec, correct, u, alt, rhs, n, c, omega, second[0], second[1])
         plo, phi_ = max(lo - 2, u.i0), min(hi + 2, u.i0 + u.planes, n[0])
         if self._oop:
             # on-load form: u itself stays as it was, the sweep sees the prolongated values
