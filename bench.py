@@ -293,7 +293,7 @@ def run_distributed(args):
         del s2
 
     base1 = None
-    if rank == 0 and not args.no_single_gpu_compare:
+    if rank == 0 and not args.no_single_gpu_compare and n <= 1025:
         from multigrid_amd import libmg
         del s
         torch.cuda.empty_cache()

@@ -392,15 +392,23 @@ class DistSolver:
     def own(self, l, kind):
         return self.plan.own(l, kind, self.rank)
 
+    UPLOAD_PLANES = 32  # host arrays are produced and uploaded this many planes at a time
+
+    def _upload(self, slab, of_planes, lo, hi):
+        for a in range(lo, hi, self.UPLOAD_PLANES):
+            b = min(a + self.UPLOAD_PLANES, hi)
+            self.ops.upload(slab, of_planes(a, b), a)
+
     def set_rho(self, rho_of_planes):
-        """rho_of_planes(lo, hi) -> dense array of global planes [lo,hi).  Stored as rho/EPS_0."""
+        """rho_of_planes(lo, hi) -> dense array of global planes [lo,hi); called for a few planes at
+        a time, so a rank never holds its whole slab in host memory.  Stored as rho/EPS_0."""
         lo, hi = self.plan.stored(0, "R", self.rank, self.H_RHS)
-        self.ops.upload(self.b, rho_of_planes(lo, hi), lo)
+        self._upload(self.b, rho_of_planes, lo, hi)
         self.ops.div_eps0(self.b)
 
     def set_phi(self, phi_of_planes):
         lo, hi = self.plan.stored(0, "phi", self.rank, self.H_U)
-        self.ops.upload(self.phi, phi_of_planes(lo, hi), lo)
+        self._upload(self.phi, phi_of_planes, lo, hi)
         self.correction_pending = False
 
     def get_phi_owned(self):
