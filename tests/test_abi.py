@@ -62,3 +62,62 @@ def test_no_silent_cpu_fallback(mg):
         mg.op_residual(np.zeros((5, 5, 5)), np.zeros((5, 5, 5)), (1e-2,) * 3)
     with pytest.raises(mg.MgError):
         mg.op_compute_ef(np.zeros((5, 5, 5)), (1e-2,) * 3)
+
+
+def _arr(mg, ptr, planes, nj, nk, i0):
+    return mg.MgDevArray(ptr, planes, nj, nk, i0)
+
+
+def test_level_coefficients_match_the_oracle(mg, orc):
+    """1/(4^l dh^2) exactly as the reference writes it (cpp/PotentialSolver.cpp:3728-3750)."""
+    dh = (0.4 / 512, 0.37 / 512, 0.41 / 512)
+    for level in range(7):
+        out = (C.c_double * 4)()
+        assert mg.load().mg_level_coef((C.c_double * 3)(*dh), level, out) == 0
+        assert tuple(out) == orc.coeffs(dh, level)
+    assert mg.load().mg_dev_pitch(513) == 514 and mg.load().mg_dev_pitch(512) == 512
+
+
+def test_slab_entry_points_validate_before_launching(mg):
+    """Argument checks of the device-level operators run on the host, before any kernel: bad plane
+    ranges, missing halo planes, misaligned pointers and mismatched twins are refused (no GPU is
+    touched, so this runs anywhere)."""
+    lib = mg.load()
+    n = (C.c_int64 * 3)(64, 40, 40)
+    c = (C.c_double * 4)(1.0, 1.0, 1.0, 6.0)
+    flag = C.c_int(0)
+    fake = 0x10000  # never dereferenced: every call below must fail validation first
+    u = _arr(mg, fake, 20, 40, 40, 10)          # planes [10, 30)
+    alt = _arr(mg, fake + 0x100000, 20, 40, 40, 10)
+    rhs = _arr(mg, fake + 0x200000, 18, 40, 40, 11)
+    cases = [
+        # sweep planes [12, 29): needs u planes up to 31, only [10,30) stored
+        lambda: lib.mg_dev_smooth_rb(None, C.byref(u), C.byref(alt), C.byref(rhs), n, c, 1.4, 1, 12, 29, 0, 0, C.byref(flag)),
+        # range outside the stored planes
+        lambda: lib.mg_dev_smooth_rb(None, C.byref(u), C.byref(alt), C.byref(rhs), n, c, 1.4, 1, 5, 20, 0, 0, C.byref(flag)),
+        # twin with another shape
+        lambda: lib.mg_dev_smooth_rb(None, C.byref(u), C.byref(_arr(mg, fake, 19, 40, 40, 10)), C.byref(rhs), n, c,
+                                     1.4, 1, 12, 28, 0, 0, C.byref(flag)),
+        # misaligned base pointer
+        lambda: lib.mg_dev_smooth_rb(None, C.byref(_arr(mg, fake + 8, 20, 40, 40, 10)), C.byref(alt), C.byref(rhs), n, c,
+                                     1.4, 1, 12, 28, 0, 0, C.byref(flag)),
+        # second range shorter than the first
+        lambda: lib.mg_dev_smooth_rb(None, C.byref(u), C.byref(alt), C.byref(rhs), n, c, 1.4, 1, 12, 14, 26, 27, C.byref(flag)),
+        # second range with more than one sweep
+        lambda: lib.mg_dev_smooth_rb(None, C.byref(u), C.byref(alt), C.byref(rhs), n, c, 1.4, 2, 12, 14, 26, 28, C.byref(flag)),
+        # fused residual must start on an even plane
+        lambda: lib.mg_dev_residual_restrict(None, C.byref(u), C.byref(rhs), C.byref(_arr(mg, fake, 10, 20, 20, 5)), n, c,
+                                             C.c_void_p(fake), 1 << 16, 13, 20, C.byref(C.c_int64(0))),
+        # prolongation without the coarse planes it interpolates from
+        lambda: lib.mg_dev_prolong(None, C.byref(_arr(mg, fake, 3, 21, 21, 9)), C.byref(u), n, 12, 28, 0),
+        # field kernel without the halo plane
+        lambda: lib.mg_dev_compute_ef(None, C.byref(u), C.c_void_p(fake), 10, n, (C.c_double * 3)(1e-3, 1e-3, 1e-3), 10, 20),
+    ]
+    for k, call in enumerate(cases):
+        assert call() == -1, f"case {k} was not refused"  # MG_ERR_INVALID
+        assert lib.mg_last_error()
+    assert lib.mg_dev_sweep_out_of_place(C.byref(_arr(mg, None, 40, 300, 300, 0))) == 1
+    assert lib.mg_dev_sweep_out_of_place(C.byref(_arr(mg, None, 40, 100, 100, 0))) == 0
+    assert lib.mg_dev_onload_folds(C.byref(_arr(mg, None, 40, 200, 200, 0)), 1) == 1   # correction: from 128 rows
+    assert lib.mg_dev_onload_folds(C.byref(_arr(mg, None, 40, 200, 200, 0)), 0) == 0   # prolongation: from 256
+    assert lib.mg_dev_onload_folds(C.byref(_arr(mg, None, 40, 300, 300, 0)), 0) == 1
