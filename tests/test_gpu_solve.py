@@ -128,6 +128,25 @@ def test_non_cubic_grid(gpu, orc):
         assert_bit_equal(h.get_phi(), phi, "phi non-cubic")
 
 
+@pytest.mark.parametrize("N,depth", [((67, 261, 133), 2), ((130, 140, 300), 3), ((40, 520, 270), 2)], ids=str)
+def test_non_cubic_grids_on_the_marching_kernels(gpu, orc, N, depth):
+    """Ragged, non-cubic sizes above 128 nodes: single-pass sweep (32- and 64-row windows), fused
+    residual+restriction and on-load correction/prolongation with windows cut by the array edges."""
+    dh = (0.01, 0.02, 0.005)
+    rho = orc.synthetic_rho(N)
+    phi = np.zeros(N)
+    s = orc.Solver(N, dh, depth)
+    ok, cyc, l2, hist = s.solve(phi, rho, 3, 0.0, rb=True)
+    with gpu.Handle(N, dh, depth) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        l2_gpu = h.vcycles(3)
+        assert_bit_equal(h.get_phi(), phi, "phi non-cubic")
+        for l in range(1, depth + 1):
+            assert_bit_equal(h.level_array("eps", l), s.eps(l), f"eps_{l}")
+    assert l2_gpu == pytest.approx(hist[-1], rel=1e-11)
+
+
 def test_state_errors(gpu):
     with gpu.Handle((41, 41, 41), (0.01,) * 3, 2) as h:
         with pytest.raises(gpu.MgError):
