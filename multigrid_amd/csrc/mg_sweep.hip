@@ -331,7 +331,11 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
             else red_phase_impl<0, Q, RPP * WK, WK>(X, v0, vm1, vp1, b0, okmask, c, omega);
         }
         if (MODE != kLoadPlain && !(f & 1)) stage_write((f >> 1) + 1, cv);
-        __syncthreads();
+        // No barrier between the phases: the black update of plane p-1 reads, from other lanes,
+        // only the red values of plane p-1 (written one iteration ago, before this iteration's
+        // barrier) in a slot nobody writes now; its i neighbours are this lane's own registers.
+        // The red values written above are first read by other lanes in the next iteration, the
+        // coarse planes staged above after the next barrier too.
         // ---- black points of plane p-1 (neighbours: new red values), store --
         const int pb = p - 1;
         if (pb >= ia && pb < ib) {
@@ -376,11 +380,11 @@ static int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
-template <int WJ, int NT>
+template <int WJ, int NT, int D = 2>
 static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec, int load_op,
                            const int64_t n[3], Coef c, double omega, IRange r, IRange r2)
 {
-    constexpr int WKP = 32, D = 2;
+    constexpr int WKP = 32;
     constexpr int TJ = WJ - 4, TK = 2 * WKP - 4;
     static const int want_chunks = env_int("MG_SWEEP_CHUNKS", 0);  // tuning knob (A/B runs)
     const int64_t planes = r.hi - r.lo;
@@ -425,6 +429,8 @@ static void launch_sweep(hipStream_t s, View uin, View uout, View rhs, View ec, 
     const int wj = (forced == 32 || forced == 64) ? forced : (uin.d[1] >= 256 ? 64 : 32);
     static const int nt = env_int("MG_SWEEP_NT", 512);
     if (wj == 64 && nt == 1024) launch_sweep_t<64, 1024>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
+    else if (wj == 64 && env_int("MG_SWEEP_D", 2) == 1) launch_sweep_t<64, 512, 1>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
+    else if (wj == 64 && env_int("MG_SWEEP_D", 2) == 3) launch_sweep_t<64, 512, 3>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
     else if (wj == 64) launch_sweep_t<64, 512>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
     else launch_sweep_t<32, 256>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
 }
