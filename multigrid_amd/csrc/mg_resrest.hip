@@ -25,6 +25,15 @@ namespace {
 
 struct alignas(16) d2 { double x, y; };
 
+// Value of the lane below (lane - 1) in the wave; lane 0 keeps its own.
+__device__ __forceinline__ double lane_left(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum64(double v)
 {
 #pragma unroll
@@ -152,49 +161,61 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
                     double(*A)[WK] = ring[(p - 2 + 3) % 3];  // plane 2I-1
                     double(*B)[WK] = ring[(p - 1) % 3];      // plane 2I
                     double(*C)[WK] = ring[p % 3];            // plane 2I+1
-                    // A thread produces up to NOUT coarse points of this plane.  Each is a chain of 26
-                    // dependent additions (the reference's order); the chains of a thread's points are
-                    // advanced together so that they overlap in the pipeline.
-                    constexpr int NOUT = (TJC * TKC + NT - 1) / NT;
-                    int rr_[NOUT], cc_[NOUT];
-                    bool live[NOUT], inject[NOUT];
-                    int64_t at_[NOUT];
+                    // 32 lanes per coarse row: lane l holds the fine pair (2l, 2l+1) of each of the nine
+                    // (di, dj) rows it needs -- one conflict-free 16-byte LDS read each -- and takes the
+                    // column to its left (2l-1) from lane l-1's pair by a wave shift.  Lanes 1..TKC
+                    // produce coarse column l-1; lanes 0 and 31 only feed their neighbours.  The terms
+                    // are added in the reference's order: dk = -1 (left column), then 0, then +1.
+                    constexpr int RPR = NT / WKP;                       // coarse rows per round
+                    constexpr int ROUNDS = (TJC + RPR - 1) / RPR;
+                    const int l = tid % WKP;
+                    const int Kl = l - 1;
+                    const int K = tk * TKC + Kl;
 #pragma unroll
-                    for (int o = 0; o < NOUT; o++) {
-                        const int t = tid + o * NT;
-                        const int tc = t < TJC * TKC ? t : 0;  // idle slots recompute point 0, never stored
-                        const int Jl = tc / TKC, Kl = tc % TKC;
-                        const int J = tj * TJC + Jl, K = tk * TKC + Kl;
-                        live[o] = t < TJC * TKC && J < cJ && K < cK;
-                        inject[o] = I == 0 || J == 0 || K == 0;
-                        rr_[o] = 2 * Jl + 2;
-                        cc_[o] = 2 * Kl + 2;
-                        at_[o] = Rc.at(I, min(J, cJ - 1), min(K, cK - 1));
+                    for (int o = 0; o < ROUNDS; o++) {
+                        const int Jl = min(tid / WKP + o * RPR, TJC - 1);   // rows past the end repeat the last one
+                        const bool rowlive = tid / WKP + o * RPR < TJC;
+                        const int J = tj * TJC + Jl;
+                        const int r = 2 * Jl + 2;
+#define PAIR(di, dj) (*reinterpret_cast<const d2 *>(&((di) < 0 ? A : (di) == 0 ? B : C)[r + (dj)][2 * l]))
+                        double v;
+                        // dk = -1: the odd column left of the pair
+                        v = lane_left(PAIR(-1, -1).y);
+                        v = v + 2 * lane_left(PAIR(0, -1).y);
+                        v = v + lane_left(PAIR(1, -1).y);
+                        v = v + 2 * lane_left(PAIR(-1, 0).y);
+                        v = v + 4 * lane_left(PAIR(0, 0).y);
+                        v = v + 2 * lane_left(PAIR(1, 0).y);
+                        v = v + lane_left(PAIR(-1, 1).y);
+                        v = v + 2 * lane_left(PAIR(0, 1).y);
+                        v = v + lane_left(PAIR(1, 1).y);
+                        // dk = 0 (pair.x) while keeping pair.y for dk = +1
+                        const d2 q0 = PAIR(-1, -1), q1 = PAIR(0, -1), q2 = PAIR(1, -1), q3 = PAIR(-1, 0), q4 = PAIR(0, 0),
+                                 q5 = PAIR(1, 0), q6 = PAIR(-1, 1), q7 = PAIR(0, 1), q8 = PAIR(1, 1);
+                        v = v + 2 * q0.x;
+                        v = v + 4 * q1.x;
+                        v = v + 2 * q2.x;
+                        v = v + 4 * q3.x;
+                        v = v + 8 * q4.x;
+                        v = v + 4 * q5.x;
+                        v = v + 2 * q6.x;
+                        v = v + 4 * q7.x;
+                        v = v + 2 * q8.x;
+                        // dk = +1
+                        v = v + q0.y;
+                        v = v + 2 * q1.y;
+                        v = v + q2.y;
+                        v = v + 2 * q3.y;
+                        v = v + 4 * q4.y;
+                        v = v + 2 * q5.y;
+                        v = v + q6.y;
+                        v = v + 2 * q7.y;
+                        v = v + q8.y;
+#undef PAIR
+                        v = v * 0.015625;  // == v / 64.0 exactly (power of two)
+                        if (I == 0 || J == 0 || K == 0) v = q4.x;  // injection: R_2h = R_h at (2I, 2J, 2K)
+                        if (rowlive && Kl >= 0 && Kl < TKC && J < cJ && K < cK) Rc.p[Rc.at(I, J, K)] = v;
                     }
-                    double v[NOUT];
-#define F(o, di, dj, dk) ((di) < 0 ? A : (di) == 0 ? B : C)[rr_[o] + (dj)][cc_[o] + (dk)]
-#define TERM1(di, dj, dk) _Pragma("unroll") for (int o = 0; o < NOUT; o++) v[o] = v[o] + F(o, di, dj, dk);
-#define TERMW(w, di, dj, dk) _Pragma("unroll") for (int o = 0; o < NOUT; o++) v[o] = v[o] + (w) * F(o, di, dj, dk);
-#pragma unroll
-                    for (int o = 0; o < NOUT; o++) v[o] = F(o, -1, -1, -1);
-                    TERMW(2, 0, -1, -1) TERM1(1, -1, -1)
-                    TERMW(2, -1, 0, -1) TERMW(4, 0, 0, -1) TERMW(2, 1, 0, -1)
-                    TERM1(-1, 1, -1) TERMW(2, 0, 1, -1) TERM1(1, 1, -1)
-                    TERMW(2, -1, -1, 0) TERMW(4, 0, -1, 0) TERMW(2, 1, -1, 0)
-                    TERMW(4, -1, 0, 0) TERMW(8, 0, 0, 0) TERMW(4, 1, 0, 0)
-                    TERMW(2, -1, 1, 0) TERMW(4, 0, 1, 0) TERMW(2, 1, 1, 0)
-                    TERM1(-1, -1, 1) TERMW(2, 0, -1, 1) TERM1(1, -1, 1)
-                    TERMW(2, -1, 0, 1) TERMW(4, 0, 0, 1) TERMW(2, 1, 0, 1)
-                    TERM1(-1, 1, 1) TERMW(2, 0, 1, 1) TERM1(1, 1, 1)
-#pragma unroll
-                    for (int o = 0; o < NOUT; o++) {
-                        const double full = v[o] * 0.015625;  // == v / 64.0 exactly (power of two)
-                        const double out = inject[o] ? B[rr_[o]][cc_[o]] : full;
-                        if (live[o]) Rc.p[at_[o]] = out;
-                    }
-#undef F
-#undef TERM1
-#undef TERMW
                 }
                 __syncthreads();  // ring slot (p-2)%3 is overwritten by plane p+1 next
             }
