@@ -34,6 +34,15 @@ __device__ __forceinline__ double lane_left(double v)
     return __hiloint2double(hi, lo);
 }
 
+// Value of the lane above (lane + 1) in the wave; lane 63 keeps its own.
+__device__ __forceinline__ double lane_right(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum64(double v)
 {
 #pragma unroll
@@ -131,8 +140,10 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
                     const d2 u = u0[q];
                     const d2 un = q == 0 ? hN0 : u0[q > 0 ? q - 1 : 0];
                     const d2 us = q == Q - 1 ? hS0 : u0[q < Q - 1 ? q + 1 : Q - 1];
-                    const double left = __shfl_up(u.y, 1, WKP);
-                    const double right = __shfl_down(u.x, 1, WKP);
+                    // k-1 / k+1 across the pair boundary: the neighbouring lane's element (at the ends of
+                    // a 32-lane row the value comes from another row: window-edge columns, never used)
+                    const double left = lane_left(u.y);
+                    const double right = lane_right(u.x);
                     d2 rr;
                     rr.x = u.x * c.d - b0[q].x - c.cx * (um1[q].x + up1[q].x) - c.cy * (un.x + us.x) -
                            c.cz * (left + u.y);
