@@ -229,8 +229,16 @@ def run_distributed(args):
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
+    # MG_BENCH_BACKEND=gloo with MG_BENCH_SHARE_GPU=1 rehearses this code path with several ranks on
+    # ONE GPU (halo planes staged through the host); the numbers of such a run mean nothing
+    backend = os.environ.get("MG_BENCH_BACKEND", "nccl")
+    if os.environ.get("MG_BENCH_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
     n = args.size or 1025
     N = (n, n, n)
     depth = args.depth or problem.reference_depth_for(N)
@@ -252,7 +260,7 @@ def run_distributed(args):
     t0 = time.perf_counter()
     l2 = s.vcycles(args.steps)
     fence()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     wall = float(dt.item())
     vps = args.steps / wall
