@@ -72,65 +72,84 @@ __global__ __launch_bounds__(256) void k_smooth_colour(View u, View rhs, int64_t
 // All sweeps of a small level inside one workgroup: u lives in LDS, the two colours are
 // separated by workgroup barriers instead of kernel boundaries.  Used for the coarsest grid,
 // whose 50 sweeps would otherwise be 100 launches of a few thousand points each.
+//
+// LDS layout: the two colours are stored apart, each as [i][j][k>>1] with H = (uK+1)/2 entries
+// per row.  The six neighbours of a point all have the other colour, and consecutive lanes
+// (consecutive points of one colour in a row) then read consecutive LDS words: no bank
+// conflicts, where a dense [i][j][k] copy is read at a stride of two doubles (half the banks).
 // Every thread keeps its points (at most P per colour) in registers for the whole launch:
 // LDS offset, right-hand side (constant over the sweeps) and current value, so a half-sweep is
 // six LDS reads, the update and one LDS write per point.
+__host__ __device__ inline size_t smooth_lds_doubles(int64_t uI, int64_t uJ, int64_t uK)
+{
+    return (size_t)(2 * uI * uJ * ((uK + 1) / 2));
+}
+
 template <int P>
 __global__ __launch_bounds__(1024) void k_smooth_lds(View u, View rhs, int nI, int nJ, int nK,
                                                      Coef c, double omega, int sweeps)
 {
-    extern __shared__ __align__(16) double su[];  // dense copy of u, strides (uJ*uK, uK, 1)
+    extern __shared__ __align__(16) double su[];
     const int uI = (int)u.d[0], uJ = (int)u.d[1], uK = (int)u.d[2];
+    const int H = (uK + 1) / 2, HALF = uI * uJ * H;
     const int tid = threadIdx.x;
+    auto lds_at = [&](int i, int j, int k) { return ((i + j + k) & 1) * HALF + (i * uJ + j) * H + (k >> 1); };
     for (int p = tid; p < uI * uJ * uK; p += 1024) {
         const int k = p % uK, j = (p / uK) % uJ, i = p / (uK * uJ);
-        su[p] = u.p[u.at(i, j, k)];
+        su[lds_at(i, j, k)] = u.p[u.at(i, j, k)];
     }
     const int half = (nK - 1) / 2;  // colour positions per row, at most
     const int rows = (nI - 2) * (nJ - 2);
-    const int si = uJ * uK, sj = uK;
-    int off[2][P];      // LDS offset of the point, -1 = none
-    double b[2][P];     // its right-hand side
+    int off[2][P];      // LDS offset of the point's (i, j, k>>1) entry in the OTHER colour's half, -1 = none
+    int kodd[2][P];     // k & 1: the k-1 / k+1 neighbours sit at entries kodd-1 and kodd of that row
+    double b[2][P];     // right-hand side
+    double cur[2][P];   // current value (only this thread changes it)
 #pragma unroll
     for (int colour = 0; colour < 2; colour++)
 #pragma unroll
         for (int q = 0; q < P; q++) {
             const int idx = tid + q * 1024;
             off[colour][q] = -1;
+            kodd[colour][q] = 0;
             b[colour][q] = 0.0;
+            cur[colour][q] = 0.0;
             if (idx < rows * half) {
                 const int m = idx % half, t = idx / half;
                 const int j = 1 + t % (nJ - 2), i = 1 + t / (nJ - 2);
                 const int k = 1 + ((i + j + 1 + colour) & 1) + 2 * m;
                 if (k <= nK - 2) {
-                    off[colour][q] = i * si + j * sj + k;
+                    off[colour][q] = (1 - colour) * HALF + (i * uJ + j) * H + (k >> 1);
+                    kodd[colour][q] = k & 1;
                     b[colour][q] = rhs.p[rhs.at(i, j, k)];
+                    cur[colour][q] = u.p[u.at(i, j, k)];
                 }
             }
         }
     __syncthreads();
+    const int si = uJ * H, sj = H;
     for (int s = 0; s < sweeps; s++) {
 #pragma unroll
         for (int colour = 0; colour < 2; colour++) {
-            double nu[P];
 #pragma unroll
             for (int q = 0; q < P; q++) {
-                const int o = off[colour][q] < 0 ? si + sj + 1 : off[colour][q];  // any interior point
+                // a thread without a point reads around some interior entry and discards the result
+                const int o = off[colour][q] < 0 ? (1 - colour) * HALF + si + sj + 1 : off[colour][q];
                 const double *p = su + o;
+                const double *pk = p + kodd[colour][q];
                 const double g = div_d(b[colour][q] + c.cx * (p[-si] + p[si]) + c.cy * (p[-sj] + p[sj]) +
-                                       c.cz * (p[-1] + p[1]), c);
-                const double u0 = p[0];
-                nu[q] = u0 + omega * (g - u0);
+                                       c.cz * (pk[-1] + pk[0]), c);
+                const double u0 = cur[colour][q];
+                cur[colour][q] = u0 + omega * (g - u0);
             }
 #pragma unroll
-            for (int q = 0; q < P; q++)
-                if (off[colour][q] >= 0) su[off[colour][q]] = nu[q];
+            for (int q = 0; q < P; q++)  // own entry: same (i, j, k>>1), this colour's half
+                if (off[colour][q] >= 0) su[off[colour][q] + (colour ? HALF : -HALF)] = cur[colour][q];
             __syncthreads();
         }
     }
     for (int p = tid; p < uI * uJ * uK; p += 1024) {
         const int k = p % uK, j = (p / uK) % uJ, i = p / (uK * uJ);
-        u.p[u.at(i, j, k)] = su[p];
+        u.p[u.at(i, j, k)] = su[lds_at(i, j, k)];
     }
 }
 
@@ -413,7 +432,7 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
     const bool whole = !pair && u->i0 == 0 && r.lo == 0 && r.hi == u->d[0] && rhs.i0 == 0;
     // small enough for one workgroup: all sweeps in a single launch, u in LDS, <= 4 points per
     // colour per thread in registers
-    const size_t lds_bytes = sizeof(double) * (size_t)(u->d[0] * u->d[1] * u->d[2]);
+    const size_t lds_bytes = sizeof(double) * smooth_lds_doubles(u->d[0], u->d[1], u->d[2]);
     const int64_t per_colour = (n[0] - 2) * (n[1] - 2) * ((n[2] - 1) / 2);
     static const bool lds_ok = [] {
         const char *e = getenv("MG_SMOOTH_LDS");
