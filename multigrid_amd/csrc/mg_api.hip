@@ -99,8 +99,8 @@ struct mg_handle {
     bool have_ef = false;
     double *partials = nullptr;
     int64_t n_partials = 0;
-    double *d_sum = nullptr;    // device scalar: sum of R_h^2
-    double *h_sum = nullptr;    // pinned host mirror
+    double *h_sum = nullptr;    // sum of R_h^2: pinned host memory the reduction kernel writes directly
+    double *d_sum = nullptr;    // the same memory as the device sees it
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bool have_rho = false, have_phi = false;
@@ -181,7 +181,8 @@ void flush_correction(mg_handle *h)
 // Step 6) of the previous iteration, if still pending, and steps 1)-2b) of this one: correct,
 // smooth the fine grid, residual, norm.  The correction phi -= P(eps_1) is folded into the first
 // fine sweep where the single-pass sweep kernel runs (one pass over phi less per iteration).
-// Leaves sum(R_h^2) in h->d_sum and queues its copy to h->h_sum.
+// Leaves sum(R_h^2) in *h->h_sum once the stream has drained (the reduction kernel stores it
+// straight into pinned host memory: no copy launch).
 void enqueue_smooth_residual(mg_handle *h)
 {
     Level &f = h->lv[0];
@@ -214,7 +215,6 @@ void enqueue_smooth_residual(mg_handle *h)
         Prof p(h, MG_T_NORM, 8.0 * (double)np);
         mgk::sum_partials(h->stream, h->partials, np, h->d_sum);
     }
-    hipMemcpyAsync(h->h_sum, h->d_sum, sizeof(double), hipMemcpyDeviceToHost, h->stream);
 }
 
 // Steps 3)-5): restrict down, (prolong, smooth) up.  Step 6), phi -= P(eps_1), is left pending:
@@ -426,9 +426,9 @@ int mg_create(const mg_config *cfg, mg_handle **out)
         if (gs > h->n_partials) h->n_partials = gs;
     }
     CREATE_TRY(hip_try(hipMalloc((void **)&h->partials, (size_t)h->n_partials * sizeof(double)), "hipMalloc(partials)"));
-    CREATE_TRY(hip_try(hipMalloc((void **)&h->d_sum, sizeof(double)), "hipMalloc(sum)"));
-    CREATE_TRY(hip_try(hipHostMalloc((void **)&h->h_sum, sizeof(double), hipHostMallocDefault), "hipHostMalloc"));
+    CREATE_TRY(hip_try(hipHostMalloc((void **)&h->h_sum, sizeof(double), hipHostMallocMapped), "hipHostMalloc"));
     *h->h_sum = 0;
+    CREATE_TRY(hip_try(hipHostGetDevicePointer((void **)&h->d_sum, h->h_sum, 0), "hipHostGetDevicePointer"));
 #undef CREATE_TRY
     *out = h;
     return MG_OK;
@@ -451,7 +451,6 @@ int mg_destroy(mg_handle *h)
     if (h->b.p) hipFree(h->b.p);
     if (h->ef) hipFree(h->ef);
     if (h->partials) hipFree(h->partials);
-    if (h->d_sum) hipFree(h->d_sum);
     if (h->h_sum) hipHostFree(h->h_sum);
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_b) hipEventDestroy(h->ev_b);
@@ -573,7 +572,6 @@ int mg_gs_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsig
                 Prof p(h, MG_T_NORM, 8.0 * (double)np);
                 mgk::sum_partials(h->stream, h->partials, np, h->d_sum);
             }
-            HIP_TRY(hipMemcpyAsync(h->h_sum, h->d_sum, sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(h->stream));
             l2 = l2_from_sum(h, *h->h_sum);
