@@ -309,27 +309,17 @@ void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const 
                        double *partials, IRange r)
 {
     const Geometry g = geometry(n, r);
-    static const int threads = [] { const char *e = getenv("MG_RR_NT"); return e ? atoi(e) : 256; }();
-    static const int depth = [] { const char *e = getenv("MG_RR_D"); return e ? atoi(e) : 2; }();
 #define LAUNCHW(WJ, D, RF, NT)                                                                        \
     hipLaunchKernelGGL((k_residual_restrict<WJ, 32, D, RF, NT>), dim3(g.order.grid()), dim3(NT), 0, s, phi, b, \
                        Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi, g.order)
-#define LAUNCH(D, RF, NT) LAUNCHW(32, D, RF, NT)
+    // Measured and not built any more: prefetch depths 1 and 3, and 512 threads on the 32-row window.
     if (window_rows(n) == 64) {
         if (Rf.p) LAUNCHW(64, 2, true, 512);
-        else if (depth == 3) LAUNCHW(64, 3, false, 512);
-        else if (depth == 1) LAUNCHW(64, 1, false, 512);
         else LAUNCHW(64, 2, false, 512);
-    } else if (Rf.p) {
-        LAUNCH(2, true, 256);
-    } else if (threads == 512) {
-        if (depth == 1) LAUNCH(1, false, 512);
-        else LAUNCH(2, false, 512);
     } else {
-        if (depth == 1) LAUNCH(1, false, 256);
-        else LAUNCH(2, false, 256);
+        if (Rf.p) LAUNCHW(32, 2, true, 256);
+        else LAUNCHW(32, 2, false, 256);
     }
-#undef LAUNCH
 #undef LAUNCHW
 }
 

@@ -427,11 +427,9 @@ static void launch_sweep(hipStream_t s, View uin, View uout, View rhs, View ec, 
     // enough windows to fill the chip.  MG_SWEEP_WJ=32|64 overrides (A/B runs).
     static const int forced = env_int("MG_SWEEP_WJ", 0);
     const int wj = (forced == 32 || forced == 64) ? forced : (uin.d[1] >= 256 ? 64 : 32);
-    static const int nt = env_int("MG_SWEEP_NT", 512);
-    if (wj == 64 && nt == 1024) launch_sweep_t<64, 1024>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
-    else if (wj == 64 && env_int("MG_SWEEP_D", 2) == 1) launch_sweep_t<64, 512, 1>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
-    else if (wj == 64 && env_int("MG_SWEEP_D", 2) == 3) launch_sweep_t<64, 512, 3>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
-    else if (wj == 64) launch_sweep_t<64, 512>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
+    // Measured at 513^3 and not built any more: 1024 threads per window and prefetch depths 1 and 3
+    // (the latter at 256 VGPRs) were slower than or level with 512 threads at depth 2.
+    if (wj == 64) launch_sweep_t<64, 512>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
     else launch_sweep_t<32, 256>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
 }
 

@@ -1,5 +1,5 @@
 """The slab-partitioned solve on CPU: the product's orchestration (multigrid_amd/dist.py: plan,
-halo exchange schedule, coarse gather/scatter, all-reduce) runs over gloo with world_size 2 and 3,
+halo exchange schedule, coarse gather/scatter, all-reduce) runs over gloo with world_size 2, 3, 4 and 8,
 with the oracle's slab-form operators standing in for the GPU kernels, and must reproduce the
 undivided red-black oracle bit for bit."""
 import os
@@ -51,7 +51,8 @@ def _worker(rank, world, port, n, depth, cut, cycles, out_dir, oop=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,depth,cut", [(2, 33, 2, 1), (2, 33, 3, 2), (3, 65, 3, 2), (2, 41, 2, 2)])
+@pytest.mark.parametrize("world,n,depth,cut", [(2, 33, 2, 1), (2, 33, 3, 2), (3, 65, 3, 2), (2, 41, 2, 2),
+                                                  (4, 65, 3, 1), (8, 65, 3, 2)])
 @pytest.mark.parametrize("oop", [0, 1, 2], ids=["in_place", "edges_exchange_interior", "exchange_completes_late"])
 def test_partitioned_cycle_equals_undivided_oracle(orc, tmp_path, world, n, depth, cut, oop):
     """oop: the operators behave like the GPU's out-of-place sweep kernel, which makes the solver
