@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm ships its own copy of the HIP runtime.  A process that uses both torch and
+# libmg_hip.so on the GPU must load torch first, so that the library binds to the runtime that is
+# already there; the other way round the process holds two runtimes and the second one to
+# initialise finds no device.  Some GPU tests use torch tensors as device buffers.
+import torch  # noqa: F401  (before anything loads libmg_hip.so)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
