@@ -424,9 +424,10 @@ static void launch_sweep(hipStream_t s, View uin, View uout, View rhs, View ec, 
                          const int64_t n[3], Coef c, double omega, IRange r, IRange r2)
 {
     // 64-row windows (512 threads) re-read fewer halo rows per owned row; they pay once a plane has
-    // enough windows to fill the chip.  MG_SWEEP_WJ=32|64 overrides (A/B runs).
+    // enough windows to fill the chip.  MG_SWEEP_WJ=32|64 and MG_SWEEP_WJ64_MIN=<rows> override (A/B runs).
     static const int forced = env_int("MG_SWEEP_WJ", 0);
-    const int wj = (forced == 32 || forced == 64) ? forced : (uin.d[1] >= 256 ? 64 : 32);
+    static const int min64 = env_int("MG_SWEEP_WJ64_MIN", 256);
+    const int wj = (forced == 32 || forced == 64) ? forced : (uin.d[1] >= min64 ? 64 : 32);
     // Measured at 513^3 and not built any more: 1024 threads per window and prefetch depths 1 and 3
     // (the latter at 256 VGPRs) were slower than or level with 512 threads at depth 2.
     if (wj == 64) launch_sweep_t<64, 512>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);
