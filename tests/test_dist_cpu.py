@@ -51,9 +51,15 @@ def _worker(rank, world, port, n, depth, cut, cycles, out_dir, oop=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,depth,cut", [(2, 33, 2, 1), (2, 33, 3, 2), (3, 65, 3, 2), (2, 41, 2, 2),
-                                                  (4, 65, 3, 1), (8, 65, 3, 2)])
-@pytest.mark.parametrize("oop", [0, 1, 2], ids=["in_place", "edges_exchange_interior", "exchange_completes_late"])
+CASES = [(w, n, d, c, oop) for (w, n, d, c) in [(2, 33, 2, 1), (2, 33, 3, 2), (3, 65, 3, 2), (2, 41, 2, 2)]
+         for oop in (0, 1, 2)]
+# more ranks (every rank but the first and last has two neighbours; 8 is the node's GPU count)
+CASES += [(4, 65, 3, 1, 1), (8, 65, 3, 2, 1), (8, 65, 3, 2, 2)]
+OOP_IDS = {0: "in_place", 1: "edges_exchange_interior", 2: "exchange_completes_late"}
+
+
+@pytest.mark.parametrize("world,n,depth,cut,oop", CASES,
+                         ids=[f"{w}-{n}-{d}-{c}-{OOP_IDS[o]}" for (w, n, d, c, o) in CASES])
 def test_partitioned_cycle_equals_undivided_oracle(orc, tmp_path, world, n, depth, cut, oop):
     """oop: the operators behave like the GPU's out-of-place sweep kernel, which makes the solver
     issue every sweep (and the fine residual) as edge planes, halo exchange, interior.  With RCCL
