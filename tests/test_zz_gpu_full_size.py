@@ -74,3 +74,29 @@ def test_two_slabs_equal_the_undivided_grid_at_1025(gpu, tmp_path):
     assert all(g is not None for g in got)
     bad = [i for i in range(N1) if got[i] != want[i]]
     assert not bad, f"planes that differ between the partitioned and the undivided solve: {bad[:8]} ..."
+
+
+def test_headline_solve_is_confirmed_by_the_oracle_residual(gpu, orc):
+    """513^3, five coarse grids, solved to 1e-6 on the GPU from phi = 0: the CPU oracle's residual
+    operator, applied to the potential the solve returned, must find the norm the solve reported
+    (the GPU sums the squares in another order: 1e-10 relative) and it must be below the
+    tolerance.  A second solve from that potential must stop at its first test."""
+    n = 513
+    N = (n, n, n)
+    dh = orc.main_extents_dh(N)
+    rho = orc.synthetic_rho(N)
+    with gpu.Handle(N, dh, 5) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        ok, cycles, l2 = h.solve(1000, 1e-6)
+        phi = h.get_phi()
+        assert ok and l2 < 1e-6
+        assert 100 <= cycles <= 125  # the lexicographic reference loop needs 119 tests here
+        _, s = orc.residual(phi, rho, orc.coeffs(dh, 0))
+        assert np.sqrt(s / float(n) ** 3) == pytest.approx(l2, rel=1e-10)
+        # Dirichlet faces untouched
+        for face in (phi[0], phi[-1], phi[:, 0], phi[:, -1], phi[:, :, 0], phi[:, :, -1]):
+            assert not face.any()
+        h.set_phi(phi)
+        ok2, cycles2, l22 = h.solve(1000, 1e-6)
+        assert ok2 and cycles2 == 1
