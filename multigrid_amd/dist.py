@@ -458,6 +458,16 @@ class DistSolver:
             edges, inner = self._split(own, first, last)
             overlap = (self.world > 1 and self.overlap and self.ops.out_of_place(u)
                        and inner[1] - inner[0] >= 2 * self.H_U)
+            # The last fine sweep is followed by the residual pass, whose interior part reads no
+            # halo plane: the sweep runs as ONE launch and its exchange under that interior part
+            # (an edge launch re-reads four lead-in planes per edge).
+            whole_then_exchange = overlap and l == 0 and sweep == self.nu[l] - 1
+            if whole_then_exchange:
+                u.ready()
+                assert run(*own), "out-of-place sweep expected"
+                self.comm.exchange_start(alt, own, self.H_U)
+                self.phi, self.phi_alt = alt, u
+                continue
             if overlap:
                 # edge planes need the halos of the previous sweep; the interior does not.  Both
                 # edges (equally long) go in one launch.
