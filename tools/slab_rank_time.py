@@ -46,10 +46,10 @@ class SoloComm(mgd.Comm):
             slab.rows(lo, hi).copy_(full.rows(lo, hi))
 
 
-def measure(n, world, rank, cycles=10):
+def measure(n, world, rank, cycles=10, overlap=True):
     N = (n, n, n)
     depth = problem.reference_depth_for(N)
-    s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, mgd.HipOps(0), SoloComm(rank, world))
+    s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, mgd.HipOps(0), SoloComm(rank, world), overlap=overlap)
     s.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
     s.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
     marks = []
@@ -103,11 +103,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=1025)
     ap.add_argument("--cases", default="8:3,8:0,4:1,2:0")
+    ap.add_argument("--no-overlap", action="store_true", help="whole-slab launches, no edge/interior split")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     for case in args.cases.split(","):
         w, r = (int(x) for x in case.split(":"))
-        res = measure(args.size, w, r)
+        res = measure(args.size, w, r, overlap=not args.no_overlap)
         print(" ".join(f"{k}={v:.3f}" if isinstance(v, float) else f"{k}={v}" for k, v in res.items()), flush=True)
 
 
