@@ -78,6 +78,19 @@ def cpu_baseline(n, depth, cycles):
     import numpy as np
     from oracle import mg_oracle as orc
     orc.build()
+    note = ""
+    if n > 513:
+        # the oracle keeps phi, rho, R_0 and eps_0 whole in host memory (4 x n^3 x 8 B plus the
+        # temporaries of the rho generator): fall back to the 513^3 sample when that does not fit
+        need = 7.0 * 8.0 * float(n) ** 3
+        try:
+            import psutil
+            avail = float(psutil.virtual_memory().available)
+        except Exception:
+            avail = 0.0
+        if avail < 1.5 * need:
+            note = f" (the {n}^3 arrays do not fit this host's free memory: 513^3 V5 sample instead)"
+            n, depth = 513, 5
     N = (n, n, n)
     dh = orc.main_extents_dh(N)
     rho = orc.synthetic_rho(N)
@@ -89,7 +102,7 @@ def cpu_baseline(n, depth, cycles):
     per = dt / cycles
     return {"value": 1.0 / per, "unit": "V-cycles/s", "cores": 1, "kind": "port",
             "sample": f"{cycles} iterations of the lexicographic (reference-order) {n}^3 V{depth} cycle, "
-                      f"gcc -O3 single thread, host has {os.cpu_count()} logical CPUs",
+                      f"gcc -O3 single thread, host has {os.cpu_count()} logical CPUs" + note,
             "s_per_cycle": per, "gdof_per_s": n ** 3 / per / 1e9}
 
 
@@ -317,7 +330,11 @@ def run_distributed(args):
         base1 = {"workload": f"{n}^3 V{depth} on one GPU of this node, same run", "ms_per_step": t1 * 1e3,
                  "vcycles_per_s": 1.0 / t1, "gdof_per_s": npts / t1 / 1e9, "speedup": vps * t1}
     dist.barrier()
+    dist.destroy_process_group()
     if rank == 0:
+        # the reference-order CPU cycle on one host core of this node, after the group is gone (the
+        # other ranks have nothing left to wait for): one iteration at this workload's size
+        cpu = cpu_baseline(n, depth, max(1, min(args.cpu_cycles, 1 if n > 513 else 3))) if args.cpu_cycles > 0 else None
         out = {"metric": "GDoF/s", "value": npts * vps / 1e9, "unit": "GDoF/s (fine-grid unknowns x V-cycles/s / 1e9)",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -325,18 +342,44 @@ def run_distributed(args):
                                       f"{world} GPUs (halo planes over RCCL send/recv, levels >= {s_cut(N, depth, world)} "
                                       f"gathered on rank 0)", "grid": n, "depth": depth,
                           "note": "N=1 runs the 513^3 headline configuration; N>=2 run 1025^3 (strong scaling among N>=2)"},
-               "vcycles_per_s": vps, "last_L2": l2, "roofline": roofline, "cpu_baseline": None, "solve": solve,
+               "vcycles_per_s": vps, "last_L2": l2, "roofline": roofline, "cpu_baseline": cpu, "solve": solve,
                "single_gpu_same_workload": base1, "halo_bytes_sent_rank0": comm.bytes_sent}
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    dist.destroy_process_group()
 
 
 def s_cut(N, depth, world):
     from multigrid_amd.dist import SlabPlan
     return SlabPlan(N, depth, world).cut
+
+
+def spawn_ranks(n_gpus):
+    """`python bench.py --gpus N` typed as is: this process has made no GPU call yet and makes none;
+    it starts one rank per GPU under torch.distributed.run with the same arguments, relays rank 0's
+    JSON line and returns the launcher's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in p.stdout:
+        if out.lstrip().startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = p.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks finished without a result line\n")
+        return 1
+    if line is not None:
+        print(line, flush=True)
+    return rc
 
 
 def main():
@@ -345,9 +388,10 @@ def main():
     if args.gpus == 1 and world == 1 and not os.environ.get("MG_BENCH_FORCE_DIST"):
         run_single(args)
         return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} needs one process per GPU: launch with "
-                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}")
     run_distributed(args)
 
 

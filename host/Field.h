@@ -3,10 +3,12 @@
 // zero-filled at construction, public const ni/nj/nk.  Written from scratch for the
 // HIP host adapter; only what the multigrid path and its driver touch is provided.
 //
-// Unlike the reference (one heap block per (i,j) row) the node data is ONE block in
-// [i][j][k] order with two pointer tables on top, so flat() can hand the whole field
-// to the device library without a packing pass.  Code that only uses f[i][j][k],
-// f(i,j,k), clear() and ni/nj/nk cannot tell the difference.
+// Unlike the reference (one heap block per (i,j) row) the node data is by default ONE block
+// in [i][j][k] order with two pointer tables on top, so the whole field can go to the device
+// library without a packing pass.  Code that only uses f[i][j][k], f(i,j,k), clear() and
+// ni/nj/nk cannot tell the difference.  Compiled with -DMG_FIELD_ROW_PER_ALLOCATION the
+// rows are separate heap blocks as in the reference (cpp/Field.h:65-70): the layout a
+// solver meets when it is built into the reference program.
 #ifndef MG_HOST_FIELD_H
 #define MG_HOST_FIELD_H
 
@@ -36,37 +38,68 @@ using int3 = vec3<int>;
 template <typename T>
 class Field_ {
 public:
-    Field_(int ni_, int nj_, int nk_)
-        : ni(ni_), nj(nj_), nk(nk_), cells(std::size_t(ni_) * nj_ * nk_), rows(std::size_t(ni_) * nj_),
-          planes(ni_)
+    Field_(int ni_, int nj_, int nk_) : ni(ni_), nj(nj_), nk(nk_), rows(std::size_t(ni_) * nj_), planes(ni_)
     {
-        for (int i = 0; i < ni; i++) {
-            planes[i] = rows.data() + std::size_t(i) * nj;
-            for (int j = 0; j < nj; j++) planes[i][j] = cells.data() + (std::size_t(i) * nj + j) * nk;
+#ifdef MG_FIELD_ROW_PER_ALLOCATION
+        // the reference's allocation pattern (cpp/Field.h:65-70): one zero-filled heap block per
+        // (i,j) row, so rows are NOT adjacent in memory
+        store.resize(rows.size());
+        for (std::size_t r = 0; r < rows.size(); r++) {
+            store[r].assign(std::size_t(nk) + r % 3, T());  // uneven block sizes keep rows apart
+            rows[r] = store[r].data();
         }
+#else
+        cells.assign(std::size_t(ni_) * nj_ * nk_, T());
+        for (std::size_t r = 0; r < rows.size(); r++) rows[r] = cells.data() + r * nk;
+#endif
+        for (int i = 0; i < ni; i++) planes[i] = rows.data() + std::size_t(i) * nj;
         data = planes.data();
     }
-    Field_(const Field_ &o) : Field_(o.ni, o.nj, o.nk) { cells = o.cells; }
+    Field_(const Field_ &o) : Field_(o.ni, o.nj, o.nk)
+    {
+        for (std::size_t r = 0; r < rows.size(); r++)
+            for (int k = 0; k < nk; k++) rows[r][k] = o.rows[r][k];
+    }
     Field_ &operator=(const Field_ &) = delete;
 
     T **operator[](int i) { return data[i]; }                          // f[i][j][k]
     T operator()(int i, int j, int k) const { return data[i][j][k]; }  // read-only access
-    void operator=(double s) { for (T &c : cells) c = T(s); }
+    void operator=(double s)
+    {
+        for (T *r : rows)
+            for (int k = 0; k < nk; k++) r[k] = T(s);
+    }
     void clear() { (*this) = 0; }
-    Field_ &operator+=(const Field_ &o) { for (std::size_t p = 0; p < cells.size(); p++) cells[p] += o.cells[p]; return *this; }
-    Field_ &operator*=(double s) { for (T &c : cells) c *= s; return *this; }
+    Field_ &operator+=(const Field_ &o)
+    {
+        for (std::size_t r = 0; r < rows.size(); r++)
+            for (int k = 0; k < nk; k++) rows[r][k] += o.rows[r][k];
+        return *this;
+    }
+    Field_ &operator*=(double s)
+    {
+        for (T *r : rows)
+            for (int k = 0; k < nk; k++) r[k] *= s;
+        return *this;
+    }
     // logical node number with i fastest (cpp/Field.h:161); not the memory order
     int U(int i, int j, int k) const { return k * ni * nj + j * ni + i; }
 
-    // the node data in memory order ((i*nj)+j)*nk+k
+    std::size_t size() const { return std::size_t(ni) * nj * nk; }
+#ifndef MG_FIELD_ROW_PER_ALLOCATION
+    // the node data in memory order ((i*nj)+j)*nk+k (not part of the reference's surface)
     T *flat() { return cells.data(); }
     const T *flat() const { return cells.data(); }
-    std::size_t size() const { return cells.size(); }
+#endif
 
     const int ni, nj, nk;
 
 protected:
+#ifdef MG_FIELD_ROW_PER_ALLOCATION
+    std::vector<std::vector<T>> store;
+#else
     std::vector<T> cells;
+#endif
     std::vector<T *> rows;
     std::vector<T **> planes;
     T ***data;

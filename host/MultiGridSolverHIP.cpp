@@ -1,6 +1,7 @@
 // Host adapter: Field_<double> <-> flat arrays <-> libmg_hip (include/mg_hip.h).
 #include "MultiGridSolverHIP.h"
 
+#include <cstdint>
 #include <cstring>
 #include <iostream>
 #include <stdexcept>
@@ -15,29 +16,52 @@ void check(int rc, const char *what)
     if (rc != MG_OK) throw std::runtime_error(std::string(what) + ": " + mg_last_error());
 }
 
-// True when the rows f[i][j] lie back to back in memory ((i*nj)+j)*nk+k -- always the case for
-// this repository's Field, never for the reference's row-per-allocation Field.
-bool rows_contiguous(Field &f)
+// True when the rows f[i][j] lie back to back in memory ((i*nj)+j)*nk+k -- the case for this
+// repository's default Field, never for the reference's row-per-allocation Field
+// (cpp/Field.h:65-70).
+template <typename F>
+bool rows_contiguous(F &f)
 {
-    const double *base = f[0][0];
+    const auto *base = f[0][0];
     for (int i = 0; i < f.ni; i++)
         for (int j = 0; j < f.nj; j++)
             if (f[i][j] != base + (std::size_t(i) * f.nj + j) * f.nk) return false;
     return true;
 }
 
-// Dense [i][j][k] image of a field: the field's own storage if contiguous, else a row-wise copy.
-const double *pack(Field &f, std::vector<double> &stage)
+// Node p of the sample that stands for "world.phi is what the device holds": 4096 nodes spread by
+// a multiplicative hash, then the six face centres and the eight corners.
+constexpr int kScattered = 4096, kSample = kScattered + 14;
+void sample_node(const Field &f, int p, int &i, int &j, int &k)
 {
-    if (rows_contiguous(f)) return f[0][0];
-    stage.resize(std::size_t(f.ni) * f.nj * f.nk);
-    for (int i = 0; i < f.ni; i++)
-        for (int j = 0; j < f.nj; j++)
-            std::memcpy(&stage[(std::size_t(i) * f.nj + j) * f.nk], f[i][j], sizeof(double) * f.nk);
-    return stage.data();
+    if (p < kScattered) {
+        const std::uint64_t total = std::uint64_t(f.ni) * f.nj * f.nk;
+        const std::uint64_t q = (std::uint64_t(p) * 0x9E3779B97F4A7C15ull >> 11) % total;
+        k = int(q % f.nk);
+        j = int(q / f.nk % f.nj);
+        i = int(q / f.nk / f.nj);
+        return;
+    }
+    p -= kScattered;
+    const int hi[3] = {f.ni - 1, f.nj - 1, f.nk - 1};
+    int c[3] = {hi[0] / 2, hi[1] / 2, hi[2] / 2};
+    if (p < 6) c[p / 2] = (p & 1) ? hi[p / 2] : 0;                                 // face centres
+    else for (int a = 0; a < 3; a++) c[a] = ((p - 6) >> a & 1) ? hi[a] : 0;        // corners
+    i = c[0]; j = c[1]; k = c[2];
 }
 
 }  // namespace
+
+// Dense [i][j][k] image of a field: the field's own storage if contiguous, else a row-wise copy
+// into the page-locked staging block.
+const double *MultiGridSolverHIP::pack(Field &f)
+{
+    if (rows_contiguous(f)) return f[0][0];
+    for (int i = 0; i < f.ni; i++)
+        for (int j = 0; j < f.nj; j++)
+            std::memcpy(stage + (std::size_t(i) * f.nj + j) * f.nk, f[i][j], sizeof(double) * f.nk);
+    return stage;
+}
 
 MultiGridSolverHIP::MultiGridSolverHIP(World &w, int max_it, double tol, int depth, int device, bool variant_b)
     : PotentialSolver(w), max_solver_it(max_it), tolerance(tol)
@@ -49,27 +73,91 @@ MultiGridSolverHIP::MultiGridSolverHIP(World &w, int max_it, double tol, int dep
     else check(mg_default_config(&cfg, world.ni, world.nj, world.nk, h, depth), "mg_default_config");
     cfg.device = device;
     check(mg_create(&cfg, &handle), "mg_create");
+    // Page-lock the fields in place where they are one block (failure only costs copy speed, e.g.
+    // when another solver on the same World has locked them already); otherwise stage through a
+    // page-locked block of our own, big enough for the three-component field.
+    const std::size_t nodes = std::size_t(world.ni) * world.nj * world.nk;
+    auto lock = [&](void *p, std::size_t bytes) {
+        if (mg_host_register(p, bytes) == MG_OK) registered.push_back(p);
+    };
+    const bool flat_fields = rows_contiguous(world.phi) && rows_contiguous(world.rho) && rows_contiguous(world.ef);
+    if (flat_fields) {
+        lock(world.phi[0][0], nodes * sizeof(double));
+        lock(world.rho[0][0], nodes * sizeof(double));
+        lock(world.ef[0][0], nodes * 3 * sizeof(double));
+    } else {
+        stage_doubles = nodes * 3;
+        void *p = nullptr;
+        if (mg_host_alloc(&p, stage_doubles * sizeof(double)) != MG_OK) {
+            mg_destroy(handle);
+            throw std::runtime_error(std::string("mg_host_alloc: ") + mg_last_error());
+        }
+        stage = static_cast<double *>(p);
+    }
 }
 
-MultiGridSolverHIP::~MultiGridSolverHIP() { mg_destroy(handle); }
+MultiGridSolverHIP::~MultiGridSolverHIP()
+{
+    mg_destroy(handle);
+    for (void *p : registered) mg_host_unregister(p);
+    if (stage) mg_host_free(stage);
+}
+
+bool MultiGridSolverHIP::device_phi_current()
+{
+    if (!device_phi_valid || phi_sample.size() != std::size_t(kSample)) return false;
+    Field &phi = world.phi;
+    for (int p = 0; p < kSample; p++) {
+        int i, j, k;
+        sample_node(phi, p, i, j, k);
+        if (std::memcmp(&phi[i][j][k], &phi_sample[p], sizeof(double)) != 0) return false;
+    }
+    return true;
+}
+
+void MultiGridSolverHIP::remember_phi()
+{
+    Field &phi = world.phi;
+    phi_sample.resize(kSample);
+    for (int p = 0; p < kSample; p++) {
+        int i, j, k;
+        sample_node(phi, p, i, j, k);
+        phi_sample[p] = phi[i][j][k];
+    }
+    device_phi_valid = true;
+}
+
+void MultiGridSolverHIP::upload_phi_if_stale()
+{
+    if (device_phi_current()) return;
+    check(mg_set_phi(handle, pack(world.phi)), "mg_set_phi");
+    phi_uploads++;
+    remember_phi();
+}
 
 bool MultiGridSolverHIP::solve()
 {
-    check(mg_set_rho(handle, pack(world.rho, stage)), "mg_set_rho");
-    check(mg_set_phi(handle, pack(world.phi, stage)), "mg_set_phi");
     int converged = 0;
-    check(iterate(&converged), "solve");
-    Field &phi = world.phi;
-    if (rows_contiguous(phi)) {
-        check(mg_get_phi(handle, phi[0][0]), "mg_get_phi");
-    } else {
-        stage.resize(std::size_t(phi.ni) * phi.nj * phi.nk);
-        check(mg_get_phi(handle, stage.data()), "mg_get_phi");
-        for (int i = 0; i < phi.ni; i++)
-            for (int j = 0; j < phi.nj; j++)
-                std::memcpy(phi[i][j], &stage[(std::size_t(i) * phi.nj + j) * phi.nk], sizeof(double) * phi.nk);
+    try {
+        check(mg_set_rho(handle, pack(world.rho)), "mg_set_rho");
+        upload_phi_if_stale();
+        device_phi_valid = false;  // until the result is back in world.phi
+        check(iterate(&converged), "solve");
+        Field &phi = world.phi;
+        if (rows_contiguous(phi)) {
+            check(mg_get_phi(handle, phi[0][0]), "mg_get_phi");
+        } else {
+            check(mg_get_phi(handle, stage), "mg_get_phi");
+            for (int i = 0; i < phi.ni; i++)
+                for (int j = 0; j < phi.nj; j++)
+                    std::memcpy(phi[i][j], stage + (std::size_t(i) * phi.nj + j) * phi.nk, sizeof(double) * phi.nk);
+        }
+        remember_phi();
+    } catch (const std::runtime_error &e) {
+        if (on_error == Throw) throw;
+        std::cerr << "MultiGridSolverHIP::solve: " << e.what() << std::endl;
+        return false;
     }
-    solved = true;
     if (!converged) std::cerr << "GS failed to converge, L2=" << last_l2 << std::endl;
     return converged != 0;
 }
@@ -84,32 +172,34 @@ int GaussSeidelSolverHIP::iterate(int *converged)
     return mg_gs_solve(handle, max_solver_it, tolerance, converged, &last_cycles, &last_l2);
 }
 
-// E = -grad(phi) from the device-resident potential.  Before the first solve() the device holds
-// no potential yet: upload world.phi first.
+// E = -grad(phi) of the CURRENT world.phi, like the reference's host loop
+// (cpp/PotentialSolver.cpp:418-458): computed on the device from the copy the last solve() left
+// there when world.phi still is that potential, after an upload otherwise.
 void MultiGridSolverHIP::computeEF()
 {
-    if (!solved) check(mg_set_phi(handle, pack(world.phi, stage)), "mg_set_phi");
-    check(mg_compute_ef(handle), "mg_compute_ef");
+    try {
+        upload_phi_if_stale();
+        check(mg_compute_ef(handle), "mg_compute_ef");
+        download_ef();
+    } catch (const std::runtime_error &e) {
+        if (on_error == Throw) throw;
+        std::cerr << "MultiGridSolverHIP::computeEF: " << e.what() << std::endl;
+    }
+}
+
+void MultiGridSolverHIP::download_ef()
+{
     Field3 &ef = world.ef;
     static_assert(sizeof(double3) == 3 * sizeof(double), "double3 must be three packed doubles");
-    const std::size_t row = std::size_t(ef.nk) * 3;
-    const double *base = reinterpret_cast<const double *>(ef[0][0]);
-    bool contiguous = true;
-    for (int i = 0; i < ef.ni && contiguous; i++)
-        for (int j = 0; j < ef.nj; j++)
-            if (reinterpret_cast<const double *>(ef[i][j]) != base + (std::size_t(i) * ef.nj + j) * row) {
-                contiguous = false;
-                break;
-            }
-    if (contiguous) {
+    if (rows_contiguous(ef)) {
         check(mg_get_ef(handle, reinterpret_cast<double *>(ef[0][0])), "mg_get_ef");
         return;
     }
-    stage.resize(std::size_t(ef.ni) * ef.nj * row);
-    check(mg_get_ef(handle, stage.data()), "mg_get_ef");
+    const std::size_t row = std::size_t(ef.nk) * 3;
+    check(mg_get_ef(handle, stage), "mg_get_ef");
     for (int i = 0; i < ef.ni; i++)
         for (int j = 0; j < ef.nj; j++)
-            std::memcpy(static_cast<void *>(ef[i][j]), &stage[(std::size_t(i) * ef.nj + j) * row], sizeof(double) * row);
+            std::memcpy(static_cast<void *>(ef[i][j]), stage + (std::size_t(i) * ef.nj + j) * row, sizeof(double) * row);
 }
 
 double MultiGridSolverHIP::deviceMilliseconds() const

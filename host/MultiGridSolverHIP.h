@@ -15,11 +15,24 @@
 // "GS failed to converge, L2=<value>" to stderr and returns false
 // (cpp/PotentialSolver.cpp:4246-4247).  Solver-private work fields persist between calls.
 // There is no CPU fallback: if the device library reports an error, solve() throws
-// std::runtime_error with the library's message.
+// std::runtime_error with the library's message (the reference's solve() never throws and its
+// driver has no handler, so the program stops with that message); setErrorPolicy(ReturnFalse)
+// makes solve() print the message to stderr and return false instead.
+//
+// Host <-> device traffic of a solve(): rho up, phi down.  The potential is uploaded only when
+// the device copy may be stale: on the first call, after invalidate(), or when a sample of
+// world.phi (4096 scattered nodes plus face centres and corners) no longer matches what the last
+// solve() returned -- in the reference's time loop phi is not written between solves
+// (cpp/Main.cpp:151-166).  Code that edits a few nodes of world.phi between solves must call
+// invalidate().  Fields whose rows are contiguous are page-locked in place for the solver's
+// lifetime, so the copies run at the full host-link rate.
 //
 // This header and MultiGridSolverHIP.cpp use only the public surface of World and Field
-// (phi, rho, getDh(), ni/nj/nk, f[i][j] row pointers), so they also compile against the
-// reference's own World.h / Field.h / PotentialSolver.h.
+// (phi, rho, ef, getDh(), ni/nj/nk, f[i][j] row pointers), so they also compile against the
+// reference's own World.h / Field.h / PotentialSolver.h, whose computeEF() is not virtual
+// (cpp/PotentialSolver.h:63): computeEF() below then hides the base version (calls through a
+// PotentialSolver* reach the host loop, which works on the downloaded phi); where the base
+// declares it virtual, as this repository's PotentialSolver.h does, it overrides it.
 #ifndef MG_HOST_MULTIGRID_SOLVER_HIP_H
 #define MG_HOST_MULTIGRID_SOLVER_HIP_H
 
@@ -41,12 +54,18 @@ public:
     MultiGridSolverHIP &operator=(const MultiGridSolverHIP &) = delete;
 
     bool solve() override;
-    void computeEF() override;
+    void computeEF();  // no `override`: the reference's base declares it non-virtual
+
+    enum ErrorPolicy { Throw, ReturnFalse };
+    void setErrorPolicy(ErrorPolicy p) { on_error = p; }
+    // world.phi was edited by someone else: upload it again at the next solve() / computeEF()
+    void invalidate() { device_phi_valid = false; }
 
     // diagnostics of the last solve()
     unsigned cycles() const { return last_cycles; }
     double residualNorm() const { return last_l2; }
     double deviceMilliseconds() const;
+    unsigned phiUploads() const { return phi_uploads; }  // how often world.phi went to the device
 
 protected:
     // iteration loop run on the device between the upload and the download of solve()
@@ -55,10 +74,22 @@ protected:
     unsigned max_solver_it;  // same names as the reference members (cpp/PotentialSolver.h:85-86)
     double tolerance;
     mg_handle *handle = nullptr;
-    std::vector<double> stage;  // dense copy of a field whose rows are not contiguous
     unsigned last_cycles = 0;
     double last_l2 = 0;
-    bool solved = false;  // the device holds the potential of the last solve()
+
+private:
+    const double *pack(Field &f);
+    bool device_phi_current();
+    void remember_phi();
+    void upload_phi_if_stale();
+    void download_ef();
+    double *stage = nullptr;         // page-locked dense image of a field whose rows are not contiguous
+    std::size_t stage_doubles = 0;
+    std::vector<void *> registered;  // host blocks this solver page-locked in place
+    std::vector<double> phi_sample;  // world.phi at the sample nodes when the device copy was last in step
+    bool device_phi_valid = false;
+    unsigned phi_uploads = 0;
+    ErrorPolicy on_error = Throw;
 };
 
 // Red-black SOR sweeps with the reference's stopping rule (norm of the interior residual tested

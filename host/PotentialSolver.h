@@ -14,7 +14,13 @@ public:
     // (cpp/PotentialSolver.cpp:418-458): host loop.  Virtual here (the reference's is not) so
     // that the device solvers can answer the driver's solver->computeEF() call
     // (cpp/Main.cpp:126,166) from the potential they still hold in device memory.
+    // -DMG_REFERENCE_COMPUTE_EF gives the reference's non-virtual declaration
+    // (cpp/PotentialSolver.h:63), to build the solvers the way the reference tree would.
+#ifdef MG_REFERENCE_COMPUTE_EF
+    void computeEF();
+#else
     virtual void computeEF();
+#endif
 
 protected:
     World &world;

@@ -7,6 +7,8 @@
 //   box_mg [n=41] [depth=2] [tol=1e-4] [--b] [--dump file] [--dump-ef file]
 //   --b selects the reference's "B" solver variant (7-point restriction);
 //   --vti file writes phi, rho and ef as VTK ImageData in the reference's ASCII format
+//   --again repeats solve() twice more: once with world.phi untouched (the device copy is reused),
+//   once after the driver has reset world.phi to zero (noticed, uploaded again);
 //   depth 0 selects the plain Gauss-Seidel/SOR solver; --dump writes phi as raw fp64 [i][j][k],
 //   --dump-ef the electric field as raw fp64 [i][j][k][3]
 #include <chrono>
@@ -25,12 +27,13 @@ int main(int argc, char **argv)
     int n = 41, depth = 2;
     double tol = 1e-4;
     const char *dump = nullptr, *dump_ef = nullptr, *vti = nullptr;
-    bool variant_b = false;
+    bool variant_b = false, again = false;
     int pos = 0;
     for (int a = 1; a < argc; a++) {
         if (!strcmp(argv[a], "--dump") && a + 1 < argc) dump = argv[++a];
         else if (!strcmp(argv[a], "--dump-ef") && a + 1 < argc) dump_ef = argv[++a];
         else if (!strcmp(argv[a], "--b")) variant_b = true;
+        else if (!strcmp(argv[a], "--again")) again = true;
         else if (!strcmp(argv[a], "--vti") && a + 1 < argc) vti = argv[++a];
         else if (pos == 0) { n = atoi(argv[a]); pos++; }
         else if (pos == 1) { depth = atoi(argv[a]); pos++; }
@@ -61,9 +64,22 @@ int main(int argc, char **argv)
         std::cout << "Simulation took " << dt.count() << " secs for solver1 to solve potential" << std::endl;
         std::cout << "converged=" << ok << " cycles=" << mg->cycles() << " L2=" << mg->residualNorm()
                   << " device_ms=" << mg->deviceMilliseconds() << std::endl;
+        if (again) {
+            const bool ok2 = solver->solve();  // phi untouched: no upload, stops at its first test
+            std::cout << "again: converged=" << ok2 << " cycles=" << mg->cycles() << " phi_uploads=" << mg->phiUploads()
+                      << std::endl;
+            world.phi.clear();                 // a new initial guess: must be noticed and uploaded
+            const bool ok3 = solver->solve();
+            solver->computeEF();
+            std::cout << "reset: converged=" << ok3 << " cycles=" << mg->cycles() << " phi_uploads=" << mg->phiUploads()
+                      << std::endl;
+        }
         if (dump) {
             FILE *f = fopen(dump, "wb");
-            if (!f || fwrite(world.phi.flat(), sizeof(double), world.phi.size(), f) != world.phi.size()) {
+            bool good = f != nullptr;
+            for (int i = 0; good && i < n; i++)
+                for (int j = 0; good && j < n; j++) good = fwrite(world.phi[i][j], sizeof(double), n, f) == size_t(n);
+            if (!good) {
                 std::cerr << "cannot write " << dump << std::endl;
                 return 3;
             }
@@ -71,7 +87,10 @@ int main(int argc, char **argv)
         }
         if (dump_ef) {
             FILE *f = fopen(dump_ef, "wb");
-            if (!f || fwrite(world.ef.flat(), sizeof(double3), world.ef.size(), f) != world.ef.size()) {
+            bool good = f != nullptr;
+            for (int i = 0; good && i < n; i++)
+                for (int j = 0; good && j < n; j++) good = fwrite(world.ef[i][j], sizeof(double3), n, f) == size_t(n);
+            if (!good) {
                 std::cerr << "cannot write " << dump_ef << std::endl;
                 return 3;
             }

@@ -159,6 +159,17 @@ int mg_gs_solve(mg_handle *h, unsigned max_it, double tol, int *converged,
 int mg_compute_ef(mg_handle *h);
 int mg_get_ef(mg_handle *h, double *ef_flat);
 
+/* Page-locked host memory for the arrays that cross the boundary.  mg_set_rho / mg_set_phi /
+ * mg_get_phi / mg_get_ef accept any host pointer; from ordinary (pageable) memory the copy is
+ * staged by the runtime at about a third of the host link's rate.  The reference keeps its
+ * fields for the whole run (World::phi, World::rho, cpp/World.h:92-96), so an integrator locks
+ * them once: mg_host_register pins caller-owned memory in place (undone by mg_host_unregister
+ * before it is freed), mg_host_alloc / mg_host_free hand out page-locked blocks. */
+int mg_host_register(void *ptr, uint64_t bytes);
+int mg_host_unregister(void *ptr);
+int mg_host_alloc(void **out, uint64_t bytes);
+int mg_host_free(void *ptr);
+
 /* Zero R_l and eps_l: the state of a freshly constructed reference solver
  * (cpp/Field.h:72).  The reference never does this after construction. */
 int mg_reset_state(mg_handle *h);

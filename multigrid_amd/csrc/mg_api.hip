@@ -20,6 +20,10 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+// Largest node count per axis: several launchers put the plane count in gridDim.z and groups of
+// four rows in gridDim.y, both limited to 65535 workgroups.
+constexpr int64_t kMaxDim = 65535;
+
 int fail(int code, const char *fmt, ...)
 {
     va_list ap;
@@ -363,7 +367,7 @@ int mg_create(const mg_config *cfg, mg_handle **out)
     const int L = cfg->depth;
     if (L < 0 || L >= MG_MAX_LEVELS) return fail(MG_ERR_INVALID, "depth %d out of range 0..%d", L, MG_MAX_LEVELS - 1);
     for (int a = 0; a < 3; a++) {
-        if (cfg->n[a] < 3 || cfg->n[a] > (int64_t)1 << 20) return fail(MG_ERR_INVALID, "n[%d]=%lld out of range", a, (long long)cfg->n[a]);
+        if (cfg->n[a] < 3 || cfg->n[a] > kMaxDim) return fail(MG_ERR_INVALID, "n[%d]=%lld out of range 3..%lld", a, (long long)cfg->n[a], (long long)kMaxDim);
         if ((cfg->n[a] >> L) < 3) return fail(MG_ERR_INVALID, "n[%d]=%lld too small for depth %d (coarsest level needs >= 3 nodes)", a, (long long)cfg->n[a], L);
         if (!(cfg->dh[a] > 0)) return fail(MG_ERR_INVALID, "dh[%d] must be positive", a);
     }
@@ -501,6 +505,7 @@ int mg_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsigned
         enqueue_smooth_residual(h);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(h->stream));
+        drain_profile(h);  // the stream is idle: fold the event pairs recorded so far into the timers
         l2 = l2_from_sum(h, *h->h_sum);
         if (l2 < tol) {
             conv = true;
@@ -574,6 +579,7 @@ int mg_gs_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsig
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(h->stream));
+            drain_profile(h);
             l2 = l2_from_sum(h, *h->h_sum);
             if (l2 < tol) {
                 conv = true;
@@ -625,6 +631,35 @@ int mg_get_ef(mg_handle *h, double *ef_flat)
     HIP_TRY(hipMemcpyAsync(ef_flat, h->ef, (size_t)count3(h->lv[0].n) * 3 * sizeof(double), hipMemcpyDeviceToHost,
                            h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return MG_OK;
+}
+
+int mg_host_register(void *ptr, uint64_t bytes)
+{
+    if (!ptr || !bytes) return fail(MG_ERR_INVALID, "mg_host_register: null pointer or zero size");
+    HIP_TRY(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    return MG_OK;
+}
+
+int mg_host_unregister(void *ptr)
+{
+    if (!ptr) return MG_OK;
+    HIP_TRY(hipHostUnregister(ptr));
+    return MG_OK;
+}
+
+int mg_host_alloc(void **out, uint64_t bytes)
+{
+    if (!out || !bytes) return fail(MG_ERR_INVALID, "mg_host_alloc: null pointer or zero size");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return MG_OK;
+}
+
+int mg_host_free(void *ptr)
+{
+    if (!ptr) return MG_OK;
+    HIP_TRY(hipHostFree(ptr));
     return MG_OK;
 }
 
@@ -733,7 +768,7 @@ int check_dims(const int64_t n[3], const char *what, int64_t lo)
 {
     if (!n) return fail(MG_ERR_INVALID, "%s: null dims", what);
     for (int a = 0; a < 3; a++)
-        if (n[a] < lo || n[a] > (int64_t)1 << 20) return fail(MG_ERR_INVALID, "%s: dim %d = %lld out of range", what, a, (long long)n[a]);
+        if (n[a] < lo || n[a] > kMaxDim) return fail(MG_ERR_INVALID, "%s: dim %d = %lld out of range", what, a, (long long)n[a]);
     return MG_OK;
 }
 
@@ -985,6 +1020,22 @@ int need_planes(const View &v, int64_t lo, int64_t hi, int64_t gmax, const char 
 
 Coef coef4(const double c[4]) { return mgk::make_coef(c[0], c[1], c[2], c[3]); }
 
+// rows and columns of a stored array must cover what the loops of an n-sized level touch
+int need_rows(const View &v, int64_t nj, int64_t nk, const char *what)
+{
+    if (v.d[1] < nj || v.d[2] < nk)
+        return fail(MG_ERR_INVALID, "%s: array has %lld x %lld rows x columns, the level needs %lld x %lld", what,
+                    (long long)v.d[1], (long long)v.d[2], (long long)nj, (long long)nk);
+    return MG_OK;
+}
+
+int check_level(const int64_t n[3], const char *what)
+{
+    for (int a = 0; a < 3; a++)
+        if (n[a] < 2 || n[a] > kMaxDim) return fail(MG_ERR_INVALID, "%s: level size %lld out of range", what, (long long)n[a]);
+    return MG_OK;
+}
+
 }  // namespace
 
 int64_t mg_dev_pitch(int64_t nk) { return mgk::pitch_for(nk); }
@@ -1046,6 +1097,9 @@ int mg_dev_smooth_rb(void *stream, const mg_dev_array *u, const mg_dev_array *al
     if (va.d[0] != vu.d[0] || va.d[1] != vu.d[1] || va.d[2] != vu.d[2] || va.i0 != vu.i0)
         return fail(MG_ERR_INVALID, "mg_dev_smooth_rb: alt must have the shape of u");
     if (lo < vu.i0 || hi > vu.i_end() || lo > hi) return fail(MG_ERR_INVALID, "mg_dev_smooth_rb: bad plane range");
+    TRY(check_level(n, "mg_dev_smooth_rb"));
+    TRY(need_rows(vu, n[1], n[2], "mg_dev_smooth_rb(u)"));
+    TRY(need_rows(vr, n[1] - 1, n[2] - 1, "mg_dev_smooth_rb(rhs)"));
     TRY(check_second_range(vu, lo, hi, lo2, hi2, sweeps, "mg_dev_smooth_rb"));
     for (int part = 0; part < (lo2 < hi2 ? 2 : 1); part++) {
         const int64_t a = part ? lo2 : lo, b = part ? hi2 : hi;
@@ -1075,6 +1129,10 @@ int mg_dev_residual_restrict(void *stream, const mg_dev_array *phi, const mg_dev
     TRY(dev_view(b, &vb, "mg_dev_residual_restrict(b)"));
     TRY(dev_view(Rc, &vc, "mg_dev_residual_restrict(Rc)"));
     if ((lo & 1) || lo < 0 || hi > n[0] || lo >= hi) return fail(MG_ERR_INVALID, "mg_dev_residual_restrict: bad plane range");
+    TRY(check_level(n, "mg_dev_residual_restrict"));
+    if (vp.d[1] != n[1] || vp.d[2] != n[2]) return fail(MG_ERR_INVALID, "mg_dev_residual_restrict: phi rows/columns must equal the level size");
+    TRY(need_rows(vb, n[1] - 1, n[2] - 1, "mg_dev_residual_restrict(b)"));
+    TRY(need_rows(vc, n[1] >> 1, n[2] >> 1, "mg_dev_residual_restrict(Rc)"));
     if ((hi & 1) && hi != n[0]) return fail(MG_ERR_INVALID, "mg_dev_residual_restrict: hi must be even or the level's last plane");
     TRY(need_planes(vp, lo - 2, hi + 1, n[0], "mg_dev_residual_restrict(phi)"));
     TRY(need_planes(vb, lo - 1, hi, n[0], "mg_dev_residual_restrict(b)"));
@@ -1107,6 +1165,10 @@ int mg_dev_restrict27(void *stream, const mg_dev_array *Rf, const mg_dev_array *
     TRY(dev_view(Rf, &vf, "mg_dev_restrict27(Rf)"));
     TRY(dev_view(Rc, &vc, "mg_dev_restrict27(Rc)"));
     if (lo < 0 || hi > (nf[0] >> 1) || lo > hi) return fail(MG_ERR_INVALID, "mg_dev_restrict27: bad plane range");
+    TRY(check_level(nf, "mg_dev_restrict27"));
+    TRY(need_rows(vf, nf[1], nf[2], "mg_dev_restrict27(Rf)"));
+    if (vc.d[1] != (nf[1] >> 1) || vc.d[2] != (nf[2] >> 1))
+        return fail(MG_ERR_INVALID, "mg_dev_restrict27: Rc rows/columns must be the fine level's size halved");
     if (lo < hi) {
         TRY(need_planes(vc, lo, hi, nf[0] >> 1, "mg_dev_restrict27(Rc)"));
         TRY(need_planes(vf, lo == 0 ? 0 : 2 * lo - 1, 2 * hi, nf[0], "mg_dev_restrict27(Rf)"));
@@ -1124,6 +1186,9 @@ int mg_dev_prolong(void *stream, const mg_dev_array *ec, const mg_dev_array *out
     TRY(dev_view(ec, &vc, "mg_dev_prolong(ec)"));
     TRY(dev_view(out, &vo, "mg_dev_prolong(out)"));
     if (lo < 0 || lo > hi) return fail(MG_ERR_INVALID, "mg_dev_prolong: bad plane range");
+    TRY(check_level(n, "mg_dev_prolong"));
+    TRY(need_rows(vo, n[1] - 1, n[2] - 1, "mg_dev_prolong(out)"));
+    TRY(need_rows(vc, (n[1] >> 1) + 1, (n[2] >> 1) + 1, "mg_dev_prolong(ec)"));
     const int64_t whi = hi > n[0] - 1 ? n[0] - 1 : hi;  // planes 0..n-2 are written
     if (lo < whi) {
         TRY(need_planes(vo, lo, whi, n[0], "mg_dev_prolong(out)"));
@@ -1149,6 +1214,9 @@ int mg_dev_prolong_smooth_rb(void *stream, const mg_dev_array *ec, int correct, 
     if (va.d[0] != vu.d[0] || va.d[1] != vu.d[1] || va.d[2] != vu.d[2] || va.i0 != vu.i0)
         return fail(MG_ERR_INVALID, "mg_dev_prolong_smooth_rb: alt must have the shape of u");
     if (lo < vu.i0 || hi > vu.i_end() || lo > hi) return fail(MG_ERR_INVALID, "mg_dev_prolong_smooth_rb: bad plane range");
+    TRY(check_level(n, "mg_dev_prolong_smooth_rb"));
+    TRY(need_rows(vu, n[1], n[2], "mg_dev_prolong_smooth_rb(u)"));
+    TRY(need_rows(vr, n[1] - 1, n[2] - 1, "mg_dev_prolong_smooth_rb(rhs)"));
     if (vc.d[1] < (n[1] >> 1) + 1 || vc.d[2] < (n[2] >> 1) + 1)
         return fail(MG_ERR_INVALID, "mg_dev_prolong_smooth_rb: coarse array smaller than (n>>1)+1");
     TRY(check_second_range(vu, lo, hi, lo2, hi2, sweeps, "mg_dev_prolong_smooth_rb"));

@@ -68,6 +68,10 @@ SYMBOLS = {
     "mg_gs_solve": (C.c_int, [_H, C.c_uint, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_uint), _dp]),
     "mg_compute_ef": (C.c_int, [_H]),
     "mg_get_ef": (C.c_int, [_H, _dp]),
+    "mg_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "mg_host_unregister": (C.c_int, [C.c_void_p]),
+    "mg_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint64]),
+    "mg_host_free": (C.c_int, [C.c_void_p]),
     "mg_reset_state": (C.c_int, [_H]),
     "mg_get_level_array": (C.c_int, [_H, C.c_int, C.c_int, _dp, _i64x3]),
     "mg_set_profiling": (C.c_int, [_H, C.c_int]),
@@ -189,20 +193,26 @@ class Handle:
     def __exit__(self, *exc):
         self.close()
 
+    @staticmethod
+    def _shape(a, want, what):
+        """The C library copies prod(want) doubles: a wrong shape must never reach it."""
+        if tuple(a.shape) != tuple(want):
+            raise ValueError(f"{what} has shape {tuple(a.shape)}, expected {tuple(want)}")
+
     def set_rho(self, rho):
         a, p = _in(rho)
-        assert a.shape == self.n
+        self._shape(a, self.n, "rho")
         _check(load().mg_set_rho(self._h, p))
 
     def set_phi(self, phi):
         a, p = _in(phi)
-        assert a.shape == self.n
+        self._shape(a, self.n, "phi")
         _check(load().mg_set_phi(self._h, p))
 
     def get_phi(self, out=None):
         if out is None:
             out = np.empty(self.n)
-        assert out.shape == self.n
+        self._shape(out, self.n, "out")
         _check(load().mg_get_phi(self._h, _out(out)))
         return out
 
@@ -244,7 +254,8 @@ class Handle:
         out = np.empty(shp)
         dims = _i64x3()
         _check(load().mg_get_level_array(self._h, w, level, _out(out), dims))
-        assert tuple(dims) == shp
+        if tuple(dims) != shp:
+            raise MgError(-102, f"level array dims {tuple(dims)} differ from the expected {shp}")
         return out
 
     def set_profiling(self, on=True):
@@ -307,7 +318,9 @@ def op_restrict7(Rf, Rc=None, device=0):
 
 def op_prolong(ec, ef, n, device=0):
     ec, pc = _in(ec)
-    assert ec.shape == tuple((a >> 1) + 1 for a in n)
+    Handle._shape(ec, tuple((a >> 1) + 1 for a in n), "ec")
+    if len(ef.shape) != 3 or any(f < a for f, a in zip(ef.shape, n)):
+        raise ValueError(f"ef has shape {tuple(ef.shape)}, needs at least {tuple(n)}")
     _check(load().mg_op_prolong(device, _i64x3(*n), _i64x3(*ef.shape), pc, _out(ef)))
     return ef
 
@@ -320,7 +333,7 @@ def op_correct(phi, eps, device=0):
 
 def op_prolong_correct(ec, phi, device=0):
     ec, pc = _in(ec)
-    assert ec.shape == tuple((a >> 1) + 1 for a in phi.shape)
+    Handle._shape(ec, tuple((a >> 1) + 1 for a in phi.shape), "ec")
     _check(load().mg_op_prolong_correct(device, _i64x3(*phi.shape), pc, _out(phi)))
     return phi
 

@@ -12,11 +12,59 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BOX = os.path.join(ROOT, "host", "box_mg")
 
 
+BOX_ROWS = os.path.join(ROOT, "host", "box_mg_rows")
+
+
 @pytest.fixture(scope="module")
 def box():
-    if not os.path.exists(BOX):
+    if not os.path.exists(BOX) or not os.path.exists(BOX_ROWS):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")], stdout=subprocess.DEVNULL)
     return BOX
+
+
+def test_adapter_compiles_against_the_reference_declarations():
+    """The reference declares computeEF() non-virtual (cpp/PotentialSolver.h:63) and allocates Field
+    rows one by one (cpp/Field.h:65-70): the adapter must build against both, warnings as errors."""
+    host = os.path.join(ROOT, "host")
+    for defs in ([], ["-DMG_REFERENCE_COMPUTE_EF"], ["-DMG_REFERENCE_COMPUTE_EF", "-DMG_FIELD_ROW_PER_ALLOCATION"]):
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only"] + defs +
+                              [os.path.join(host, "MultiGridSolverHIP.cpp"), os.path.join(host, "box_mg.cpp")])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,depth", [(41, 2), (33, 0)])
+def test_reference_field_layout_gives_the_same_bits(box, gpu, tmp_path, n, depth):
+    """box_mg_rows is the driver built the way the reference tree would build it: every Field row its
+    own heap block (the adapter packs and unpacks row by row through its page-locked staging block)
+    and PotentialSolver::computeEF non-virtual (the call through the base pointer runs the host loop
+    on the downloaded phi).  phi and E must equal the contiguous-Field build's bit for bit."""
+    outs = {}
+    for exe in (BOX, BOX_ROWS):
+        tag = os.path.basename(exe)
+        phi, ef = tmp_path / f"{tag}.phi", tmp_path / f"{tag}.ef"
+        p = subprocess.run([exe, str(n), str(depth), "1e-6", "--dump", str(phi), "--dump-ef", str(ef)],
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        outs[tag] = (np.fromfile(phi), np.fromfile(ef), [l for l in p.stdout.splitlines() if "converged=" in l][0].split()[:2])
+    a, b = outs["box_mg"], outs["box_mg_rows"]
+    assert a[2] == b[2]
+    assert_bit_equal(b[0], a[0], "phi through row-per-allocation Fields")
+    assert_bit_equal(b[1], a[1], "E through row-per-allocation Fields")
+    assert a[0].size == n ** 3 and np.abs(a[0]).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exe", [BOX, BOX_ROWS], ids=["contiguous", "rows"])
+def test_phi_is_uploaded_only_when_it_changed(box, gpu, exe):
+    """Second solve() with world.phi untouched: no upload, converged at the first test.  Third after
+    the driver zeroed world.phi: noticed by the sample check, uploaded, solved again."""
+    p = subprocess.run([exe, "41", "2", "1e-6", "--again"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    lines = {l.split(":")[0]: dict(kv.split("=") for kv in l.split(":")[1].split()) for l in p.stdout.splitlines()
+             if l.startswith(("again:", "reset:"))}
+    assert lines["again"] == {"converged": "1", "cycles": "1", "phi_uploads": "1"}
+    assert lines["reset"]["converged"] == "1" and lines["reset"]["phi_uploads"] == "2"
+    assert int(lines["reset"]["cycles"]) > 10
 
 
 def test_driver_fails_loudly_without_gpu(box, mg):
