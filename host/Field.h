@@ -13,6 +13,7 @@
 #define MG_HOST_FIELD_H
 
 #include <cstddef>
+#include <new>
 #include <ostream>
 #include <vector>
 
@@ -35,6 +36,13 @@ template <typename T> std::ostream &operator<<(std::ostream &o, const vec3<T> &v
 using double3 = vec3<double>;
 using int3 = vec3<int>;
 
+// Where the node blocks of contiguous Fields come from.  Null (the default) means operator new;
+// a driver may point the pair at a page-locked allocator (mg_host_alloc / mg_host_free of
+// libmg_hip) BEFORE it constructs its World, so that host <-> device copies of the fields run at
+// the full host-link rate.  The pair must stay set until the last Field is gone.
+inline void *(*field_block_alloc)(std::size_t bytes) = nullptr;
+inline void (*field_block_free)(void *) = nullptr;
+
 template <typename T>
 class Field_ {
 public:
@@ -49,8 +57,17 @@ public:
             rows[r] = store[r].data();
         }
 #else
-        cells.assign(std::size_t(ni_) * nj_ * nk_, T());
-        for (std::size_t r = 0; r < rows.size(); r++) rows[r] = cells.data() + r * nk;
+        const std::size_t count = std::size_t(ni_) * nj_ * nk_;
+        if (field_block_alloc) {
+            cells = static_cast<T *>(field_block_alloc(count * sizeof(T)));
+            release = field_block_free;
+        }
+        if (!cells) {
+            cells = static_cast<T *>(::operator new(count * sizeof(T)));
+            release = nullptr;
+        }
+        for (std::size_t p = 0; p < count; p++) new (cells + p) T();
+        for (std::size_t r = 0; r < rows.size(); r++) rows[r] = cells + r * nk;
 #endif
         for (int i = 0; i < ni; i++) planes[i] = rows.data() + std::size_t(i) * nj;
         data = planes.data();
@@ -61,6 +78,13 @@ public:
             for (int k = 0; k < nk; k++) rows[r][k] = o.rows[r][k];
     }
     Field_ &operator=(const Field_ &) = delete;
+#ifndef MG_FIELD_ROW_PER_ALLOCATION
+    ~Field_()
+    {
+        if (release) release(cells);
+        else ::operator delete(cells);
+    }
+#endif
 
     T **operator[](int i) { return data[i]; }                          // f[i][j][k]
     T operator()(int i, int j, int k) const { return data[i][j][k]; }  // read-only access
@@ -88,8 +112,8 @@ public:
     std::size_t size() const { return std::size_t(ni) * nj * nk; }
 #ifndef MG_FIELD_ROW_PER_ALLOCATION
     // the node data in memory order ((i*nj)+j)*nk+k (not part of the reference's surface)
-    T *flat() { return cells.data(); }
-    const T *flat() const { return cells.data(); }
+    T *flat() { return cells; }
+    const T *flat() const { return cells; }
 #endif
 
     const int ni, nj, nk;
@@ -98,7 +122,8 @@ protected:
 #ifdef MG_FIELD_ROW_PER_ALLOCATION
     std::vector<std::vector<T>> store;
 #else
-    std::vector<T> cells;
+    T *cells = nullptr;  // trivially destructible node types only (double, int, vec3)
+    void (*release)(void *) = nullptr;
 #endif
     std::vector<T *> rows;
     std::vector<T **> planes;

@@ -7,6 +7,7 @@
 //   box_mg [n=41] [depth=2] [tol=1e-4] [--b] [--dump file] [--dump-ef file]
 //   --b selects the reference's "B" solver variant (7-point restriction);
 //   --vti file writes phi, rho and ef as VTK ImageData in the reference's ASCII format
+//   --pageable keeps the World's fields in ordinary memory (default: page-locked blocks);
 //   --again repeats solve() twice more: once with world.phi untouched (the device copy is reused),
 //   once after the driver has reset world.phi to zero (noticed, uploaded again);
 //   depth 0 selects the plain Gauss-Seidel/SOR solver; --dump writes phi as raw fp64 [i][j][k],
@@ -19,21 +20,35 @@
 #include <exception>
 #include <iostream>
 
+#include "../include/mg_hip.h"
 #include "MultiGridSolverHIP.h"
 #include "Output.h"
+
+#ifndef MG_FIELD_ROW_PER_ALLOCATION
+namespace {
+// page-locked node blocks for the World's fields (see field_block_alloc in Field.h)
+void *pinned_alloc(std::size_t bytes)
+{
+    void *p = nullptr;
+    return mg_host_alloc(&p, bytes) == MG_OK ? p : nullptr;
+}
+void pinned_free(void *p) { mg_host_free(p); }
+}  // namespace
+#endif
 
 int main(int argc, char **argv)
 {
     int n = 41, depth = 2;
     double tol = 1e-4;
     const char *dump = nullptr, *dump_ef = nullptr, *vti = nullptr;
-    bool variant_b = false, again = false;
+    bool variant_b = false, again = false, pageable = false;
     int pos = 0;
     for (int a = 1; a < argc; a++) {
         if (!strcmp(argv[a], "--dump") && a + 1 < argc) dump = argv[++a];
         else if (!strcmp(argv[a], "--dump-ef") && a + 1 < argc) dump_ef = argv[++a];
         else if (!strcmp(argv[a], "--b")) variant_b = true;
         else if (!strcmp(argv[a], "--again")) again = true;
+        else if (!strcmp(argv[a], "--pageable")) pageable = true;
         else if (!strcmp(argv[a], "--vti") && a + 1 < argc) vti = argv[++a];
         else if (pos == 0) { n = atoi(argv[a]); pos++; }
         else if (pos == 1) { depth = atoi(argv[a]); pos++; }
@@ -41,6 +56,12 @@ int main(int argc, char **argv)
     }
     std::cout << "Using mesh size : " << n << "x" << n << "x" << n << std::endl;
     try {
+#ifndef MG_FIELD_ROW_PER_ALLOCATION
+        if (!pageable) {
+            field_block_alloc = pinned_alloc;
+            field_block_free = pinned_free;
+        }
+#endif
         World world(n, n, n);
         world.setExtents({-0.2, -0.2, -0.1}, {0.2, 0.2, 0.3});
         world.setBoundaries();
@@ -62,6 +83,7 @@ int main(int argc, char **argv)
         solver->computeEF();
         std::chrono::duration<double> dt = t1 - t0;
         std::cout << "Simulation took " << dt.count() << " secs for solver1 to solve potential" << std::endl;
+        (void)pageable;
         std::cout << "converged=" << ok << " cycles=" << mg->cycles() << " L2=" << mg->residualNorm()
                   << " device_ms=" << mg->deviceMilliseconds() << std::endl;
         if (again) {

@@ -637,7 +637,11 @@ int mg_get_ef(mg_handle *h, double *ef_flat)
 int mg_host_register(void *ptr, uint64_t bytes)
 {
     if (!ptr || !bytes) return fail(MG_ERR_INVALID, "mg_host_register: null pointer or zero size");
-    HIP_TRY(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // the caller may carry on with pageable memory: leave no sticky error behind
+        return fail(MG_ERR_HIP, "hipHostRegister(%p, %llu): %s", ptr, (unsigned long long)bytes, hipGetErrorString(e));
+    }
     return MG_OK;
 }
 

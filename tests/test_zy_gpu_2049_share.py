@@ -103,4 +103,6 @@ def test_middle_rank_share_of_2049_cubed(gpu, orc):
     got_rc = d_rc.cpu().numpy()
     assert _equal_bits(got_rc[colo - clo:cohi - clo, :, :nc], rc_want[colo - clo:cohi - clo, :, :nc]), \
         "restricted residual of the slab differs from the oracle"
-    assert float(total.item()) == pytest.approx(s_want, rel=1e-12)  # summation order differs
+    # 1.07e9 squares: the oracle adds them one by one (rounding error up to ~sqrt(N) ulp), the
+    # device in a tree of partial sums; the restricted residual above is the bit-exact check
+    assert float(total.item()) == pytest.approx(s_want, rel=1e-10)
