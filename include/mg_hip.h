@@ -291,6 +291,18 @@ int mg_dev_residual_restrict(void *stream, const mg_dev_array *phi, const mg_dev
                              const mg_dev_array *Rc, const int64_t n[3], const double c[4],
                              double *partials, int64_t capacity, int64_t lo, int64_t hi,
                              int64_t *count);
+/* mg_dev_residual_restrict + mg_dev_sum_partials for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  The per-workgroup partial sums go to a workspace built into the
+ * library (a 1 MiB array in each device's global memory, held until the process ends) and
+ * sumsq[0] (device memory, or mapped host memory) receives their sum in the same fixed order, so
+ * Rc and the sum are bit-identical to the two-call form.  The call allocates and frees nothing.
+ * A plane range whose launch has more than 131072 workgroups is rejected with MG_ERR_INVALID
+ * (2049 x 2049 planes in chunks of up to 64 stay below that).  All calls on one device share the
+ * workspace: calls that overlap in time on one device (different streams or threads) race. */
+int mg_dev_residual_restrict_noalloc(void *stream, const mg_dev_array *phi, const mg_dev_array *b,
+                                     const mg_dev_array *Rc, const int64_t n[3], const double c[4],
+                                     int64_t lo, int64_t hi, double *sumsq);
 /* out[0] = sum(partials[0..count)), fixed order. */
 int mg_dev_sum_partials(void *stream, const double *partials, int64_t count, double *out);
 /* Coarse planes [lo,hi) of Rc = restrict27(Rf); nf = size of the fine level. Reads Rf planes [2lo-1, 2hi). */

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -1151,6 +1152,59 @@ int mg_dev_residual_restrict(void *stream, const mg_dev_array *phi, const mg_dev
     HIP_TRY(hipGetLastError());
     *count = np;
     return MG_OK;
+}
+
+namespace {
+
+// Workspace of mg_dev_residual_restrict_noalloc: the per-workgroup partial sums.  One copy of the
+// array exists on every device the library's code object is loaded on, at its own address; the
+// name below is only the host-side handle of the symbol, never a device address.
+constexpr int64_t kNoAllocPartials = 1 << 17;  // 1 MiB
+static __device__ __align__(256) double scratch[kNoAllocPartials];
+
+constexpr int kMaxScratchDevices = 64;
+double *g_scratch_ptr[kMaxScratchDevices];  // device address of `scratch` per device ordinal
+std::mutex g_scratch_mutex;
+
+// Device address of the current device's copy of `scratch`, looked up once per device.
+int scratch_address(double **out)
+{
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxScratchDevices) return fail(MG_ERR_INVALID, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(MG_ERR_HIP, "hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = (double *)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return MG_OK;
+}
+
+}  // namespace
+
+int mg_dev_residual_restrict_noalloc(void *stream, const mg_dev_array *phi, const mg_dev_array *b,
+                                     const mg_dev_array *Rc, const int64_t n[3], const double c[4], int64_t lo,
+                                     int64_t hi, double *sumsq)
+{
+    if (!n || !sumsq) return fail(MG_ERR_INVALID, "null argument");
+    TRY(check_level(n, "mg_dev_residual_restrict_noalloc"));
+    if (lo < hi) {
+        const int64_t np = mgk::residual_restrict_partials(n, IRange{lo, hi});
+        if (np > kNoAllocPartials)
+            return fail(MG_ERR_INVALID,
+                        "mg_dev_residual_restrict_noalloc: %lld workgroup partial sums exceed the built-in workspace of "
+                        "%lld; split the plane range or use mg_dev_residual_restrict with a caller-owned buffer",
+                        (long long)np, (long long)kNoAllocPartials);
+    }
+    double *ws = nullptr;
+    TRY(scratch_address(&ws));
+    int64_t count = 0;
+    // every partial the sum reads is written by the launch before it: nothing needs clearing
+    TRY(mg_dev_residual_restrict(stream, phi, b, Rc, n, c, ws, kNoAllocPartials, lo, hi, &count));
+    return mg_dev_sum_partials(stream, ws, count, sumsq);
 }
 
 int mg_dev_sum_partials(void *stream, const double *partials, int64_t count, double *out)

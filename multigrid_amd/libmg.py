@@ -99,6 +99,9 @@ SYMBOLS = {
     "mg_dev_residual_restrict": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.POINTER(MgDevArray),
                                            C.POINTER(MgDevArray), _i64x3, C.c_double * 4, C.c_void_p, C.c_int64,
                                            C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
+    "mg_dev_residual_restrict_noalloc": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.POINTER(MgDevArray),
+                                                   C.POINTER(MgDevArray), _i64x3, C.c_double * 4, C.c_int64,
+                                                   C.c_int64, C.c_void_p]),
     "mg_dev_sum_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mg_dev_restrict27": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.POINTER(MgDevArray), _i64x3,
                                     C.c_int64, C.c_int64]),
