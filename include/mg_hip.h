@@ -30,8 +30,9 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 1
+#define MG_ABI_VERSION 2
 #define MG_MAX_LEVELS 12 /* fine grid + up to 11 coarse grids */
+#define MG_MAX_GPUS 16   /* ranks of one slab-partitioned solve */
 
 typedef enum mg_status {
     MG_OK = 0,
@@ -39,7 +40,8 @@ typedef enum mg_status {
     MG_ERR_HIP = -2,       /* a HIP runtime call failed */
     MG_ERR_NOMEM = -3,     /* device or host allocation failed */
     MG_ERR_NO_DEVICE = -4, /* no usable gfx950 device */
-    MG_ERR_STATE = -5      /* call out of order (e.g. solve before set_rho) */
+    MG_ERR_STATE = -5,     /* call out of order (e.g. solve before set_rho) */
+    MG_ERR_COMM = -6       /* RCCL failed or is unavailable, or another rank of the group failed */
 } mg_status;
 
 typedef struct mg_handle mg_handle;
@@ -55,7 +57,14 @@ typedef struct mg_handle mg_handle;
  *            :3298-3307, :3759-3770)
  *   omega   SOR factor, 1.4 in the reference (cpp/PotentialSolver.cpp:3786)
  *   device  HIP device ordinal
- *   flags   0, or MG_FLAG_* bits */
+ *   flags   0, or MG_FLAG_* bits
+ *   n_gpus  0 or 1: the whole grid on `device`.  2..MG_MAX_GPUS: the grid is split into slabs of
+ *           i-planes over devices[0..n_gpus) and solved by one host thread per GPU inside the
+ *           library (halo planes over RCCL send/recv; when an ordinal repeats in devices[], over
+ *           device-to-device copies, which lets the partitioned path run on one GPU).  Such a
+ *           handle serves mg_set_rho / mg_set_phi / mg_solve / mg_vcycle(s) / mg_get_phi /
+ *           mg_last_call_ms / mg_destroy; depth >= 1, flags == 0.
+ *   coarse_cut  first level held whole on devices[0] (0 = the first one with <= 128 planes) */
 typedef struct mg_config {
     int64_t n[3];
     double dh[3];
@@ -64,6 +73,9 @@ typedef struct mg_config {
     double omega;
     int32_t device;
     int32_t flags;  /* MG_FLAG_* */
+    int32_t n_gpus;
+    int32_t devices[MG_MAX_GPUS];
+    int32_t coarse_cut;
 } mg_config;
 
 /* Keep the fine-grid residual R_h in device memory, as the reference does
@@ -335,6 +347,54 @@ int mg_dev_onload_folds(const mg_dev_array *u, int correct);
  * planes [lo-1, hi+1), plus plane 2 when lo == 0 and plane n-3 when hi == n. */
 int mg_dev_compute_ef(void *stream, const mg_dev_array *phi, void *ef, int64_t ef_i0,
                       const int64_t n[3], const double dh[3], int64_t lo, int64_t hi);
+
+/* ---- slab-partitioned solve, one rank per GPU --------------------------------
+ * The cycle of mg_solve on a grid whose i-planes are divided among `world` ranks, each bound to
+ * one GPU and driven by one host thread or process.  No counterpart in the reference (one CPU
+ * thread, cpp/PotentialSolver.cpp:3756-4216); results are bit-identical to the undivided handle.
+ * Every rank of a group makes the same sequence of mg_dist_* calls (create, vcycles / solve,
+ * destroy are collective).  Halo planes travel by RCCL send/recv (MG_TRANSPORT_RCCL: rank 0 makes
+ * a unique id with mg_dist_unique_id, the caller hands the same 128 bytes to every rank -- over
+ * MPI, a TCP store, torch.distributed, or plain memory between threads), or between ranks that are
+ * threads of one process by device-to-device copies (MG_TRANSPORT_LOCAL with a shared
+ * mg_local_group; ranks may share a GPU). */
+#define MG_UNIQUE_ID_BYTES 128
+#define MG_TRANSPORT_RCCL 0
+#define MG_TRANSPORT_LOCAL 1
+typedef struct mg_dist mg_dist;
+typedef struct mg_local_group mg_local_group;
+typedef struct mg_dist_config {
+    mg_config base;      /* the GLOBAL grid (n, dh, depth, nu, omega); device = this rank's GPU; flags 0 */
+    int32_t rank, world;
+    int32_t coarse_cut;  /* levels >= this are gathered on rank 0; 0 = first level with <= 128 planes */
+    int32_t transport;   /* MG_TRANSPORT_* */
+    int32_t no_overlap;  /* 1: exchange halos after whole sweeps instead of under their interior part */
+    uint8_t unique_id[MG_UNIQUE_ID_BYTES];  /* MG_TRANSPORT_RCCL */
+    mg_local_group *local_group;            /* MG_TRANSPORT_LOCAL */
+} mg_dist_config;
+
+int mg_dist_unique_id(uint8_t out[MG_UNIQUE_ID_BYTES]);
+/* hold_back != 0: every halo exchange completes only when its planes are next needed (the latest
+ * moment the schedule allows) instead of when it is started -- for tests of the schedule. */
+int mg_local_group_create(int world, int hold_back, mg_local_group **out);
+int mg_local_group_destroy(mg_local_group *g);
+int mg_dist_create(const mg_dist_config *cfg, mg_dist **out);
+int mg_dist_destroy(mg_dist *d);
+/* The rank's share: *cut, the fine planes it owns [own[0], own[1]), and the planes of phi and of
+ * rho it stores and must be given (owned + halo planes). */
+int mg_dist_plan(mg_dist *d, int32_t *cut, int64_t own[2], int64_t stored_phi[2], int64_t stored_rho[2]);
+/* Dense host planes [lo,hi) of the global arrays, rows of nk doubles; any sub-range of the stored
+ * planes, so a rank never needs its whole slab in host memory.  rho is stored as rho/EPS_0. */
+int mg_dist_set_rho_planes(mg_dist *d, int64_t lo, int64_t hi, const double *dense);
+int mg_dist_set_phi_planes(mg_dist *d, int64_t lo, int64_t hi, const double *dense);
+/* Planes [lo,hi) within the owned range. */
+int mg_dist_get_phi_planes(mg_dist *d, int64_t lo, int64_t hi, double *dense);
+/* As mg_vcycles / mg_solve; every rank receives the same norm and the same stopping decision. */
+int mg_dist_vcycles(mg_dist *d, unsigned count, double *L2);
+int mg_dist_solve(mg_dist *d, unsigned max_it, double tol, int *converged, unsigned *cycles, double *L2);
+int mg_dist_sync(mg_dist *d);
+/* Device time of the last vcycles/solve call and bytes this rank has sent so far. */
+int mg_dist_stats(mg_dist *d, double *last_ms, uint64_t *bytes_sent);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 // C ABI of libmg_hip (declared in include/mg_hip.h): solver handle, cycle
 // driver and the single-operator test entry points.
 #include "../../include/mg_hip.h"
+#include "mg_internal.h"
 #include "mg_kernels.h"
 
 #include <cmath>
@@ -11,6 +12,8 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 using mgk::Coef;
@@ -34,12 +37,31 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+}  // namespace
+
+int mgk::set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
         if (e_ != hipSuccess)                                                                \
             return fail(e_ == hipErrorOutOfMemory ? MG_ERR_NOMEM : MG_ERR_HIP, "%s: %s (%s:%d)", \
                         #expr, hipGetErrorString(e_), __FILE__, __LINE__);                   \
+    } while (0)
+
+#define TRY(expr)            \
+    do {                     \
+        int rc_ = (expr);    \
+        if (rc_) return rc_; \
     } while (0)
 
 int select_device(int device)
@@ -94,7 +116,15 @@ struct Level {
 
 }  // namespace
 
+// A handle created with n_gpus > 1: one slab-partitioned rank per GPU, each driven by a host
+// thread of its own for the duration of a call.
+struct MultiGpu {
+    std::vector<mg_dist *> ranks;
+    mg_local_group *group = nullptr;  // in-process transport (an ordinal repeats in devices[])
+};
+
 struct mg_handle {
+    MultiGpu *multi = nullptr;
     mg_config cfg;
     int L;
     Level lv[MG_MAX_LEVELS];
@@ -257,6 +287,97 @@ double l2_from_sum(const mg_handle *h, double sum)
     return std::sqrt(sum / (double)count3(h->lv[0].n));
 }
 
+// Runs f(rank) for every rank of a multi-GPU handle, each on a host thread of its own (the calls
+// are collective: every rank must be inside the call for any of them to finish).
+template <typename F>
+int on_all_ranks(MultiGpu *m, F f)
+{
+    const int n = (int)m->ranks.size();
+    std::vector<int> rc(n, 0);
+    std::vector<std::string> err(n);
+    std::vector<std::thread> th;
+    for (int r = 0; r < n; r++)
+        th.emplace_back([&, r] {
+            rc[r] = f(r);
+            if (rc[r]) err[r] = g_err;  // g_err is per thread
+        });
+    for (auto &t : th) t.join();
+    for (int r = 0; r < n; r++)
+        if (rc[r]) return fail(rc[r], "rank %d: %s", r, err[r].c_str());
+    return MG_OK;
+}
+
+int single_gpu_only(const mg_handle *h, const char *what)
+{
+    if (h && h->multi) return fail(MG_ERR_STATE, "%s is not available on a multi-GPU handle", what);
+    return MG_OK;
+}
+
+int create_multi(const mg_config *cfg, mg_handle **out)
+{
+    const int n = cfg->n_gpus;
+    if (n > MG_MAX_GPUS) return fail(MG_ERR_INVALID, "n_gpus %d exceeds %d", n, MG_MAX_GPUS);
+    if (cfg->depth < 1) return fail(MG_ERR_INVALID, "a multi-GPU handle needs at least one coarse grid");
+    if (cfg->flags) return fail(MG_ERR_INVALID, "a multi-GPU handle supports no MG_FLAG_* options");
+    bool distinct = true;
+    for (int a = 0; a < n; a++)
+        for (int b = a + 1; b < n; b++)
+            if (cfg->devices[a] == cfg->devices[b]) distinct = false;
+    mg_handle *h = new (std::nothrow) mg_handle();
+    if (!h) return fail(MG_ERR_NOMEM, "host allocation failed");
+    h->cfg = *cfg;
+    h->L = cfg->depth;
+    h->multi = new (std::nothrow) MultiGpu();
+    if (!h->multi) {
+        delete h;
+        return fail(MG_ERR_NOMEM, "host allocation failed");
+    }
+    MultiGpu *m = h->multi;
+    m->ranks.assign(n, nullptr);
+    mg_dist_config dc;
+    memset(&dc, 0, sizeof(dc));
+    dc.base = *cfg;
+    dc.base.n_gpus = 0;
+    dc.world = n;
+    dc.coarse_cut = cfg->coarse_cut;
+    int rc = MG_OK;
+    if (distinct) {
+        dc.transport = MG_TRANSPORT_RCCL;
+        rc = mg_dist_unique_id(dc.unique_id);
+    } else {
+        dc.transport = MG_TRANSPORT_LOCAL;
+        rc = mg_local_group_create(n, 0, &m->group);
+        dc.local_group = m->group;
+    }
+    if (!rc)
+        rc = on_all_ranks(m, [&](int r) {
+            mg_dist_config mine = dc;
+            mine.rank = r;
+            mine.base.device = cfg->devices[r];
+            return mg_dist_create(&mine, &m->ranks[r]);
+        });
+    if (rc) {
+        mg_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return MG_OK;
+}
+
+// dense global array <-> the ranks' slabs
+int multi_upload(mg_handle *h, const double *flat, bool rho)
+{
+    const size_t plane = (size_t)h->cfg.n[1] * (size_t)h->cfg.n[2];
+    return on_all_ranks(h->multi, [&](int r) {
+        int64_t sp[2], sr[2];
+        int rc = mg_dist_plan(h->multi->ranks[r], nullptr, nullptr, sp, sr);
+        if (rc) return rc;
+        const int64_t *st = rho ? sr : sp;
+        return rho ? mg_dist_set_rho_planes(h->multi->ranks[r], st[0], st[1], flat + (size_t)st[0] * plane)
+                   : mg_dist_set_phi_planes(h->multi->ranks[r], st[0], st[1], flat + (size_t)st[0] * plane);
+    });
+}
+
 int check_ready(mg_handle *h, bool multigrid = true)
 {
     if (!h) return fail(MG_ERR_INVALID, "null handle");
@@ -365,6 +486,8 @@ int mg_create(const mg_config *cfg, mg_handle **out)
 {
     if (!cfg || !out) return fail(MG_ERR_INVALID, "null argument");
     *out = nullptr;
+    if (cfg->n_gpus < 0) return fail(MG_ERR_INVALID, "n_gpus %d is negative", cfg->n_gpus);
+    if (cfg->n_gpus > 1) return create_multi(cfg, out);
     const int L = cfg->depth;
     if (L < 0 || L >= MG_MAX_LEVELS) return fail(MG_ERR_INVALID, "depth %d out of range 0..%d", L, MG_MAX_LEVELS - 1);
     for (int a = 0; a < 3; a++) {
@@ -442,6 +565,14 @@ int mg_create(const mg_config *cfg, mg_handle **out)
 int mg_destroy(mg_handle *h)
 {
     if (!h) return MG_OK;
+    if (h->multi) {
+        // collective like creation: the RCCL communicators are torn down together
+        on_all_ranks(h->multi, [&](int r) { return mg_dist_destroy(h->multi->ranks[r]); });
+        mg_local_group_destroy(h->multi->group);
+        delete h->multi;
+        delete h;
+        return MG_OK;
+    }
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto &r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -467,6 +598,11 @@ int mg_destroy(mg_handle *h)
 int mg_set_rho(mg_handle *h, const double *rho_flat)
 {
     if (!h || !rho_flat) return fail(MG_ERR_INVALID, "null argument");
+    if (h->multi) {
+        int rc = multi_upload(h, rho_flat, true);
+        if (!rc) h->have_rho = true;
+        return rc;
+    }
     HIP_TRY(hipSetDevice(h->cfg.device));
     int rc = upload(h, rho_flat, h->b, true);
     if (rc) return rc;
@@ -477,6 +613,11 @@ int mg_set_rho(mg_handle *h, const double *rho_flat)
 int mg_set_phi(mg_handle *h, const double *phi_flat)
 {
     if (!h || !phi_flat) return fail(MG_ERR_INVALID, "null argument");
+    if (h->multi) {
+        int rc = multi_upload(h, phi_flat, false);
+        if (!rc) h->have_phi = true;
+        return rc;
+    }
     HIP_TRY(hipSetDevice(h->cfg.device));
     int rc = upload(h, phi_flat, h->phi, false);
     if (rc) return rc;
@@ -489,12 +630,36 @@ int mg_get_phi(mg_handle *h, double *phi_flat)
 {
     if (!h || !phi_flat) return fail(MG_ERR_INVALID, "null argument");
     if (!h->have_phi) return fail(MG_ERR_STATE, "no phi on the device yet");
+    if (h->multi) {
+        const size_t plane = (size_t)h->cfg.n[1] * (size_t)h->cfg.n[2];
+        return on_all_ranks(h->multi, [&](int r) {
+            int64_t own[2];
+            int rc = mg_dist_plan(h->multi->ranks[r], nullptr, own, nullptr, nullptr);
+            if (rc) return rc;
+            return mg_dist_get_phi_planes(h->multi->ranks[r], own[0], own[1], phi_flat + (size_t)own[0] * plane);
+        });
+    }
     HIP_TRY(hipSetDevice(h->cfg.device));
     return download(h, phi_flat, h->phi);
 }
 
 int mg_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsigned *cycles, double *L2)
 {
+    if (h && h->multi) {
+        if (!h->have_rho || !h->have_phi) return fail(MG_ERR_STATE, "mg_set_rho and mg_set_phi must be called before solving");
+        const int n = (int)h->multi->ranks.size();
+        std::vector<int> conv(n, 0);
+        std::vector<unsigned> cyc(n, 0);
+        std::vector<double> l2(n, 0.0);
+        int rc = on_all_ranks(h->multi, [&](int r) {
+            return mg_dist_solve(h->multi->ranks[r], max_it, tol, &conv[r], &cyc[r], &l2[r]);
+        });
+        if (rc) return rc;
+        if (converged) *converged = conv[0];  // the decision is taken on the all-reduced norm: equal on all ranks
+        if (cycles) *cycles = cyc[0];
+        if (L2) *L2 = l2[0];
+        return MG_OK;
+    }
     int rc = check_ready(h);
     if (rc) return rc;
     bool conv = false;
@@ -530,6 +695,14 @@ int mg_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsigned
 
 int mg_vcycles(mg_handle *h, unsigned count, double *L2)
 {
+    if (h && h->multi) {
+        if (!h->have_rho || !h->have_phi) return fail(MG_ERR_STATE, "mg_set_rho and mg_set_phi must be called before solving");
+        std::vector<double> l2(h->multi->ranks.size(), 0.0);
+        int rc = on_all_ranks(h->multi, [&](int r) { return mg_dist_vcycles(h->multi->ranks[r], count, &l2[r]); });
+        if (rc) return rc;
+        if (L2) *L2 = l2[0];
+        return MG_OK;
+    }
     int rc = check_ready(h);
     if (rc) return rc;
     h->have_ef = false;
@@ -553,7 +726,9 @@ int mg_vcycle(mg_handle *h, double *L2) { return mg_vcycles(h, 1, L2); }
 
 int mg_gs_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsigned *iterations, double *L2)
 {
-    int rc = check_ready(h, false);
+    int rc = single_gpu_only(h, "mg_gs_solve");
+    if (rc) return rc;
+    rc = check_ready(h, false);
     if (rc) return rc;
     Level &f = h->lv[0];
     const double N = (double)count3(f.n);
@@ -604,6 +779,7 @@ int mg_gs_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsig
 int mg_compute_ef(mg_handle *h)
 {
     if (!h) return fail(MG_ERR_INVALID, "null handle");
+    TRY(single_gpu_only(h, "mg_compute_ef"));
     if (!h->have_phi) return fail(MG_ERR_STATE, "no phi on the device yet");
     HIP_TRY(hipSetDevice(h->cfg.device));
     const int64_t *n = h->lv[0].n;
@@ -627,6 +803,7 @@ int mg_compute_ef(mg_handle *h)
 int mg_get_ef(mg_handle *h, double *ef_flat)
 {
     if (!h || !ef_flat) return fail(MG_ERR_INVALID, "null argument");
+    TRY(single_gpu_only(h, "mg_get_ef"));
     if (!h->have_ef) return fail(MG_ERR_STATE, "mg_compute_ef has not run on the current phi");
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipMemcpyAsync(ef_flat, h->ef, (size_t)count3(h->lv[0].n) * 3 * sizeof(double), hipMemcpyDeviceToHost,
@@ -671,6 +848,7 @@ int mg_host_free(void *ptr)
 int mg_reset_state(mg_handle *h)
 {
     if (!h) return fail(MG_ERR_INVALID, "null handle");
+    TRY(single_gpu_only(h, "mg_reset_state"));
     HIP_TRY(hipSetDevice(h->cfg.device));
     for (int l = 0; l <= h->L; l++) {
         if (h->lv[l].R.p) HIP_TRY(hipMemsetAsync(h->lv[l].R.p, 0, (size_t)h->lv[l].R.elems() * sizeof(double), h->stream));
@@ -683,6 +861,7 @@ int mg_reset_state(mg_handle *h)
 int mg_get_level_array(mg_handle *h, int which, int level, double *out_flat, int64_t dims_out[3])
 {
     if (!h || !out_flat) return fail(MG_ERR_INVALID, "null argument");
+    TRY(single_gpu_only(h, "mg_get_level_array"));
     if (level < 0 || level > h->L) return fail(MG_ERR_INVALID, "level %d out of range", level);
     if (which != 0 && which != 1) return fail(MG_ERR_INVALID, "which must be 0 (R) or 1 (eps)");
     if (which == 1 && level == 0) return fail(MG_ERR_INVALID, "eps_0 is not materialised on the device");
@@ -701,6 +880,7 @@ int mg_get_level_array(mg_handle *h, int which, int level, double *out_flat, int
 int mg_set_profiling(mg_handle *h, int on)
 {
     if (!h) return fail(MG_ERR_INVALID, "null handle");
+    TRY(single_gpu_only(h, "mg_set_profiling"));
     drain_profile(h);
     h->profiling = on != 0;
     return MG_OK;
@@ -709,6 +889,7 @@ int mg_set_profiling(mg_handle *h, int on)
 int mg_get_timers(mg_handle *h, mg_timers *out)
 {
     if (!h || !out) return fail(MG_ERR_INVALID, "null argument");
+    TRY(single_gpu_only(h, "mg_get_timers"));
     drain_profile(h);
     *out = h->timers;
     return MG_OK;
@@ -717,6 +898,7 @@ int mg_get_timers(mg_handle *h, mg_timers *out)
 int mg_reset_timers(mg_handle *h)
 {
     if (!h) return fail(MG_ERR_INVALID, "null handle");
+    TRY(single_gpu_only(h, "mg_reset_timers"));
     drain_profile(h);
     memset(&h->timers, 0, sizeof(h->timers));
     return MG_OK;
@@ -725,6 +907,7 @@ int mg_reset_timers(mg_handle *h)
 int mg_last_call_ms(mg_handle *h, double *ms)
 {
     if (!h || !ms) return fail(MG_ERR_INVALID, "null argument");
+    if (h->multi) return mg_dist_stats(h->multi->ranks[0], ms, nullptr);
     *ms = h->last_ms;
     return MG_OK;
 }
@@ -776,12 +959,6 @@ int check_dims(const int64_t n[3], const char *what, int64_t lo)
         if (n[a] < lo || n[a] > kMaxDim) return fail(MG_ERR_INVALID, "%s: dim %d = %lld out of range", what, a, (long long)n[a]);
     return MG_OK;
 }
-
-#define TRY(expr)           \
-    do {                    \
-        int rc_ = (expr);   \
-        if (rc_) return rc_; \
-    } while (0)
 
 int reduce_to_host(double *partials, int64_t count, double *out)
 {

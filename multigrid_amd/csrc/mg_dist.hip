@@ -1,0 +1,1069 @@
+// Slab-partitioned multigrid solve: one rank per GPU, driven from C++ inside libmg_hip
+// (mg_dist_* in include/mg_hip.h).
+//
+// The reference is a single-threaded CPU program (cpp/PotentialSolver.cpp:3756-4216); nothing
+// here has a counterpart in it.  What is distributed is the cycle the single-GPU handle runs,
+// operator by operator, with results bit-identical to the undivided red-black cycle:
+//
+//   * the i axis (slowest; planes are contiguous, so a halo is one message) of every level
+//     l < cut is split into slabs whose fine-plane boundaries are multiples of 2^cut, so the
+//     coarse slabs nest and the fused residual+restriction always starts on an even plane;
+//   * a rank stores its planes plus halo planes: 2 for swept fields (phi, eps_l), 1 for
+//     right-hand sides (b, R_l).  A red-black sweep recomputes the red update of the first halo
+//     plane on either side, so ONE exchange of two planes per side per sweep replaces an
+//     exchange after every colour;
+//   * the sweep kernel is out of place, so a sweep is issued as (1) the two planes next to each
+//     neighbour, (2) start of the exchange of exactly those planes on the communication stream,
+//     (3) the interior -- which reads no halo plane of the previous sweep -- and the next reader
+//     of the halos waits for the transfer.  The fine residual+restriction is split the same way;
+//   * the sum of squared residuals is all-reduced once per cycle;
+//   * level `cut` and everything below it is gathered onto rank 0, solved there on whole arrays
+//     with the single-GPU kernels, and eps_cut is scattered back.
+//
+// Transports: RCCL (ncclSend/ncclRecv/ncclAllReduce on a stream of its own, ordered against the
+// kernel stream with events; librccl is loaded on first use, so single-GPU users never need
+// it), and an in-process one for several ranks (host threads) that share one GPU or one
+// address space: device-to-device copies between the ranks' slabs behind host barriers.  The
+// in-process transport can hold every started exchange back until its slab is next needed --
+// the latest moment the schedule allows -- which is how the tests pin the schedule's
+// dependencies without a multi-GPU node.
+#include "../../include/mg_hip.h"
+#include "mg_internal.h"
+#include "mg_kernels.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only; the library is bound with dlopen
+
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+using mgk::Coef;
+using mgk::IRange;
+using mgk::View;
+
+#define FAIL(code, ...) return mgk::set_error(code, __VA_ARGS__)
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return mgk::set_error(e_ == hipErrorOutOfMemory ? MG_ERR_NOMEM : MG_ERR_HIP, "%s: %s (%s:%d)", #expr, \
+                                  hipGetErrorString(e_), __FILE__, __LINE__);                      \
+    } while (0)
+#define TRY(expr)            \
+    do {                     \
+        int rc_ = (expr);    \
+        if (rc_) return rc_; \
+    } while (0)
+
+namespace {
+
+// ---------------------------------------------------------------------------- RCCL binding
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+// librccl, loaded once.  A process that has PyTorch-ROCm loaded gets PyTorch's copy (same
+// soname), so both talk to one library.
+const Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+#define BIND(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.lib, "nccl" #f))
+        BIND(GetUniqueId);
+        BIND(CommInitRank);
+        BIND(CommDestroy);
+        BIND(Send);
+        BIND(Recv);
+        BIND(AllReduce);
+        BIND(GroupStart);
+        BIND(GroupEnd);
+        BIND(GetErrorString);
+#undef BIND
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Send || !r.Recv || !r.AllReduce ||
+            !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+            dlclose(r.lib);
+            r.lib = nullptr;
+        }
+    });
+    return r.lib ? &r : nullptr;
+}
+
+#define NCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess)                                                                           \
+            return mgk::set_error(MG_ERR_COMM, "%s: %s (%s:%d)", #expr, rccl()->GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------- plan
+
+// Who owns which planes of which level.  Pure arithmetic.
+struct Plan {
+    int64_t n0[3];
+    int depth, world, cut;
+    std::vector<int64_t> bounds;  // fine-plane boundaries: rank r owns [bounds[r], bounds[r+1])
+
+    int init(const int64_t n[3], int depth_, int world_, int cut_)
+    {
+        for (int a = 0; a < 3; a++) n0[a] = n[a];
+        depth = depth_;
+        world = world_;
+        if (depth < 1) FAIL(MG_ERR_INVALID, "a partitioned solve needs at least one coarse grid");
+        int64_t nmin = n0[0] < n0[1] ? n0[0] : n0[1];
+        if (n0[2] < nmin) nmin = n0[2];
+        if ((nmin >> depth) < 3) FAIL(MG_ERR_INVALID, "grid too small for depth %d", depth);
+        if (cut_ <= 0) {  // first level small enough to live on one GPU, at least 1
+            cut_ = depth;
+            for (int l = 1; l <= depth; l++)
+                if ((n0[0] >> l) <= 128) {
+                    cut_ = l;
+                    break;
+                }
+        }
+        if (cut_ < 1 || cut_ > depth) FAIL(MG_ERR_INVALID, "coarse_cut %d outside 1..depth", cut_);
+        cut = cut_;
+        const int64_t align = (int64_t)1 << cut;
+        const int64_t base = ((n0[0] - 1) / world) / align * align;
+        if (base < align)
+            FAIL(MG_ERR_INVALID, "%lld planes over %d ranks leave fewer than 2^%d fine planes per rank; lower coarse_cut or the rank count",
+                 (long long)n0[0], world, cut);
+        bounds.resize(world + 1);
+        for (int r = 0; r < world; r++) bounds[r] = r * base;
+        bounds[world] = n0[0];
+        return MG_OK;
+    }
+    void level_n(int l, int64_t out[3]) const
+    {
+        for (int a = 0; a < 3; a++) out[a] = n0[a] >> l;
+    }
+    // global plane count of an array of level l: eps arrays of l >= 1 have one extra node
+    int64_t planes(int l, bool eps) const { return (n0[0] >> l) + ((eps && l >= 1) ? 1 : 0); }
+    void dims(int l, bool eps, int64_t out[3]) const
+    {
+        level_n(l, out);
+        if (eps && l >= 1)
+            for (int a = 0; a < 3; a++) out[a] += 1;
+    }
+    IRange own(int l, bool eps, int rank) const
+    {
+        return IRange{bounds[rank] >> l, rank == world - 1 ? planes(l, eps) : bounds[rank + 1] >> l};
+    }
+    IRange stored(int l, bool eps, int rank, int halo) const
+    {
+        IRange o = own(l, eps, rank);
+        const int64_t top = planes(l, eps);
+        return IRange{o.lo - halo < 0 ? 0 : o.lo - halo, o.hi + halo > top ? top : o.hi + halo};
+    }
+};
+
+// ---------------------------------------------------------------------------- storage
+
+// Planes [v.i0, v.i0 + v.d[0]) of a level's array on this rank's GPU.
+struct Slab {
+    View v{};
+    // a halo exchange into this slab that has been started and not yet waited for
+    bool pending = false;
+    hipEvent_t done = nullptr;  // RCCL transport: recorded on the communication stream
+    IRange held_own{0, 0};      // in-process transport holding the exchange back: what to do at the wait
+    int held_width = 0;
+
+    double *plane(int64_t i) const { return v.p + (i - v.i0) * v.si; }
+    size_t plane_bytes() const { return (size_t)v.si * sizeof(double); }
+};
+
+// ---------------------------------------------------------------------------- transports
+
+struct Transport {
+    int rank = 0, world = 1;
+    uint64_t bytes_sent = 0;
+    virtual ~Transport() {}
+    // Exchange `width` halo planes per side of `s` around the owned range `own` with the slab
+    // neighbours; ordered after everything enqueued on `compute` so far.  finish() makes
+    // `compute` wait for it.
+    virtual int start(Slab &s, IRange own, int width, hipStream_t compute) = 0;
+    virtual int finish(Slab &s, hipStream_t compute) = 0;
+    // *dev_scalar = sum over ranks, same bits on every rank
+    virtual int allreduce(double *dev_scalar, hipStream_t compute) = 0;
+    // owned planes of level-l array `mine` of every rank -> rank 0's whole array
+    virtual int gather(const Plan &p, int l, bool eps, const Slab &mine, Slab *full, hipStream_t compute) = 0;
+    // rank 0's whole array -> every rank's stored planes (owned + halo)
+    virtual int scatter(const Plan &p, int l, bool eps, const Slab *full, Slab &mine, int halo, hipStream_t compute) = 0;
+};
+
+int copy_planes(Slab &dst, const View &src, IRange r, hipStream_t s)
+{
+    if (r.hi <= r.lo) return MG_OK;
+    const double *from = src.p + (r.lo - src.i0) * src.si;
+    HIP_TRY(hipMemcpyAsync(dst.plane(r.lo), from, (size_t)(r.hi - r.lo) * dst.plane_bytes(), hipMemcpyDefault, s));
+    return MG_OK;
+}
+
+// ---- RCCL
+
+struct RcclTransport : Transport {
+    const Rccl *api = nullptr;
+    ncclComm_t comm = nullptr;
+    hipStream_t cs = nullptr;         // every RCCL call of this rank goes to this stream, in issue order
+    hipEvent_t to_cs = nullptr, from_cs = nullptr;
+
+    ~RcclTransport() override
+    {
+        if (cs) hipStreamSynchronize(cs);
+        if (comm && api) api->CommDestroy(comm);
+        if (to_cs) hipEventDestroy(to_cs);
+        if (from_cs) hipEventDestroy(from_cs);
+        if (cs) hipStreamDestroy(cs);
+    }
+    int init(int rank_, int world_, const uint8_t id_bytes[MG_UNIQUE_ID_BYTES])
+    {
+        rank = rank_;
+        world = world_;
+        api = rccl();
+        if (!api) FAIL(MG_ERR_COMM, "librccl could not be loaded (or lacks the send/recv entry points)");
+        static_assert(sizeof(ncclUniqueId) == MG_UNIQUE_ID_BYTES, "unique id size");
+        ncclUniqueId id;
+        memcpy(&id, id_bytes, sizeof(id));
+        HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&to_cs, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&from_cs, hipEventDisableTiming));
+        NCCL_TRY(api->CommInitRank(&comm, world, id, rank));
+        return MG_OK;
+    }
+    int order_after_compute(hipStream_t compute)
+    {
+        HIP_TRY(hipEventRecord(to_cs, compute));
+        HIP_TRY(hipStreamWaitEvent(cs, to_cs, 0));
+        return MG_OK;
+    }
+    int compute_waits(hipStream_t compute)
+    {
+        HIP_TRY(hipEventRecord(from_cs, cs));
+        HIP_TRY(hipStreamWaitEvent(compute, from_cs, 0));
+        return MG_OK;
+    }
+    int start(Slab &s, IRange own, int w, hipStream_t compute) override
+    {
+        TRY(finish(s, compute));
+        if (world == 1) return MG_OK;
+        if (!s.done) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        TRY(order_after_compute(compute));
+        const size_t count = (size_t)w * (size_t)s.v.si;
+        NCCL_TRY(api->GroupStart());
+        if (rank + 1 < world) {
+            NCCL_TRY(api->Send(s.plane(own.hi - w), count, ncclDouble, rank + 1, comm, cs));
+            NCCL_TRY(api->Recv(s.plane(own.hi), count, ncclDouble, rank + 1, comm, cs));
+            bytes_sent += count * 8;
+        }
+        if (rank > 0) {
+            NCCL_TRY(api->Send(s.plane(own.lo), count, ncclDouble, rank - 1, comm, cs));
+            NCCL_TRY(api->Recv(s.plane(own.lo - w), count, ncclDouble, rank - 1, comm, cs));
+            bytes_sent += count * 8;
+        }
+        NCCL_TRY(api->GroupEnd());
+        HIP_TRY(hipEventRecord(s.done, cs));
+        s.pending = true;
+        return MG_OK;
+    }
+    int finish(Slab &s, hipStream_t compute) override
+    {
+        if (!s.pending) return MG_OK;
+        HIP_TRY(hipStreamWaitEvent(compute, s.done, 0));
+        s.pending = false;
+        return MG_OK;
+    }
+    int allreduce(double *x, hipStream_t compute) override
+    {
+        if (world == 1) return MG_OK;
+        TRY(order_after_compute(compute));
+        NCCL_TRY(api->AllReduce(x, x, 1, ncclDouble, ncclSum, comm, cs));
+        return compute_waits(compute);
+    }
+    int gather(const Plan &p, int l, bool eps, const Slab &mine, Slab *full, hipStream_t compute) override
+    {
+        if (rank == 0) TRY(copy_planes(*full, mine.v, p.own(l, eps, 0), compute));
+        if (world == 1) return MG_OK;
+        TRY(order_after_compute(compute));
+        NCCL_TRY(api->GroupStart());
+        if (rank == 0) {
+            for (int r = 1; r < world; r++) {
+                const IRange o = p.own(l, eps, r);
+                NCCL_TRY(api->Recv(full->plane(o.lo), (size_t)(o.hi - o.lo) * full->v.si, ncclDouble, r, comm, cs));
+            }
+        } else {
+            const IRange o = p.own(l, eps, rank);
+            NCCL_TRY(api->Send(mine.plane(o.lo), (size_t)(o.hi - o.lo) * mine.v.si, ncclDouble, 0, comm, cs));
+            bytes_sent += (uint64_t)(o.hi - o.lo) * mine.v.si * 8;
+        }
+        NCCL_TRY(api->GroupEnd());
+        return compute_waits(compute);
+    }
+    int scatter(const Plan &p, int l, bool eps, const Slab *full, Slab &mine, int halo, hipStream_t compute) override
+    {
+        if (rank == 0) TRY(copy_planes(mine, full->v, p.stored(l, eps, 0, halo), compute));
+        if (world == 1) return MG_OK;
+        TRY(order_after_compute(compute));
+        NCCL_TRY(api->GroupStart());
+        if (rank == 0) {
+            for (int r = 1; r < world; r++) {
+                const IRange o = p.stored(l, eps, r, halo);
+                NCCL_TRY(api->Send(full->plane(o.lo), (size_t)(o.hi - o.lo) * full->v.si, ncclDouble, r, comm, cs));
+                bytes_sent += (uint64_t)(o.hi - o.lo) * full->v.si * 8;
+            }
+        } else {
+            const IRange o = p.stored(l, eps, rank, halo);
+            NCCL_TRY(api->Recv(mine.plane(o.lo), (size_t)(o.hi - o.lo) * mine.v.si, ncclDouble, 0, comm, cs));
+        }
+        NCCL_TRY(api->GroupEnd());
+        return compute_waits(compute);
+    }
+};
+
+}  // namespace
+
+// ---- in-process: ranks are host threads of one process
+
+// Meeting point of the ranks of one in-process group.
+struct mg_local_group {
+    int world = 1;
+    bool hold_back = false;  // complete every started exchange only at its wait
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool broken = false;  // a rank failed: everybody still waiting is released with an error
+    std::vector<const View *> post;
+    std::vector<double> value;
+
+    // Returns false when the group was broken (a rank left with an error).
+    bool barrier()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        if (broken) return false;
+        const uint64_t gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            generation++;
+            cv.notify_all();
+            return true;
+        }
+        cv.wait(lock, [&] { return generation != gen || broken; });
+        return !broken;
+    }
+    void abandon()
+    {
+        std::lock_guard<std::mutex> lock(m);
+        broken = true;
+        cv.notify_all();
+    }
+};
+
+namespace {
+
+struct LocalTransport : Transport {
+    mg_local_group *g = nullptr;
+
+    int meet()
+    {
+        if (!g->barrier()) FAIL(MG_ERR_COMM, "another rank of the in-process group failed");
+        return MG_OK;
+    }
+    // on any failure release the ranks waiting at a barrier instead of leaving them hung
+    int guard(int rc)
+    {
+        if (rc) g->abandon();
+        return rc;
+    }
+    int exchange_now(Slab &s, IRange own, int w, hipStream_t compute)
+    {
+        HIP_TRY(hipStreamSynchronize(compute));
+        g->post[rank] = &s.v;
+        TRY(meet());
+        if (rank + 1 < world) {
+            TRY(copy_planes(s, *g->post[rank + 1], IRange{own.hi, own.hi + w}, compute));
+            bytes_sent += (uint64_t)w * s.v.si * 8;
+        }
+        if (rank > 0) {
+            TRY(copy_planes(s, *g->post[rank - 1], IRange{own.lo - w, own.lo}, compute));
+            bytes_sent += (uint64_t)w * s.v.si * 8;
+        }
+        HIP_TRY(hipStreamSynchronize(compute));
+        return meet();  // nobody overwrites what a neighbour is still copying
+    }
+    int start(Slab &s, IRange own, int w, hipStream_t compute) override
+    {
+        TRY(finish(s, compute));
+        if (world == 1) return MG_OK;
+        if (g->hold_back) {
+            s.pending = true;
+            s.held_own = own;
+            s.held_width = w;
+            return MG_OK;
+        }
+        return guard(exchange_now(s, own, w, compute));
+    }
+    int finish(Slab &s, hipStream_t compute) override
+    {
+        if (!s.pending) return MG_OK;
+        s.pending = false;
+        return guard(exchange_now(s, s.held_own, s.held_width, compute));
+    }
+    int allreduce_now(double *x, hipStream_t compute)
+    {
+        double mine = 0;
+        HIP_TRY(hipMemcpyAsync(&mine, x, sizeof(double), hipMemcpyDeviceToHost, compute));
+        HIP_TRY(hipStreamSynchronize(compute));
+        g->value[rank] = mine;
+        TRY(meet());
+        double sum = 0;
+        for (int r = 0; r < world; r++) sum += g->value[r];  // rank order: the same bits everywhere
+        TRY(meet());
+        HIP_TRY(hipMemcpyAsync(x, &sum, sizeof(double), hipMemcpyHostToDevice, compute));
+        HIP_TRY(hipStreamSynchronize(compute));
+        return MG_OK;
+    }
+    int allreduce(double *x, hipStream_t compute) override
+    {
+        if (world == 1) return MG_OK;
+        return guard(allreduce_now(x, compute));
+    }
+    int gather_now(const Plan &p, int l, bool eps, const Slab &mine, Slab *full, hipStream_t compute)
+    {
+        HIP_TRY(hipStreamSynchronize(compute));
+        g->post[rank] = &mine.v;
+        TRY(meet());
+        if (rank == 0)
+            for (int r = 0; r < world; r++) TRY(copy_planes(*full, *g->post[r], p.own(l, eps, r), compute));
+        HIP_TRY(hipStreamSynchronize(compute));
+        return meet();
+    }
+    int gather(const Plan &p, int l, bool eps, const Slab &mine, Slab *full, hipStream_t compute) override
+    {
+        if (world == 1) return copy_planes(*full, mine.v, p.own(l, eps, 0), compute);
+        return guard(gather_now(p, l, eps, mine, full, compute));
+    }
+    int scatter_now(const Plan &p, int l, bool eps, const Slab *full, Slab &mine, int halo, hipStream_t compute)
+    {
+        HIP_TRY(hipStreamSynchronize(compute));
+        if (rank == 0) g->post[0] = &full->v;
+        TRY(meet());
+        TRY(copy_planes(mine, *g->post[0], p.stored(l, eps, rank, halo), compute));
+        HIP_TRY(hipStreamSynchronize(compute));
+        return meet();
+    }
+    int scatter(const Plan &p, int l, bool eps, const Slab *full, Slab &mine, int halo, hipStream_t compute) override
+    {
+        if (world == 1) return copy_planes(mine, full->v, p.stored(l, eps, 0, halo), compute);
+        return guard(scatter_now(p, l, eps, full, mine, halo, compute));
+    }
+};
+
+constexpr int H_U = 2, H_RHS = 1;  // halo planes of swept fields / of right-hand sides
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- one rank
+
+struct mg_dist {
+    Plan plan;
+    int rank = 0, world = 1, L = 0, cut = 0, device = 0;
+    bool overlap = true;
+    int nu[MG_MAX_LEVELS] = {};
+    Coef c[MG_MAX_LEVELS];
+    double omega = 1.4;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    Transport *tr = nullptr;
+    Slab phi, phi_alt, b;
+    Slab R[MG_MAX_LEVELS], eps[MG_MAX_LEVELS], eps_alt[MG_MAX_LEVELS];     // distributed levels 1..cut
+    Slab cR[MG_MAX_LEVELS], ceps[MG_MAX_LEVELS], ceps_alt[MG_MAX_LEVELS];  // whole levels cut..L, rank 0 only
+    std::vector<void *> blocks;  // every device allocation of this rank
+    double *partials = nullptr;
+    int64_t n_partials = 0;
+    double *d_sum = nullptr;  // this rank's, then the global, sum of squared residuals
+    double *h_sum = nullptr;  // pinned
+    double n_nodes = 0;
+    bool correction_pending = false, have_rho = false, have_phi = false;
+    double last_ms = 0;
+
+    int alloc(Slab *s, int l, bool eps_kind, IRange st)
+    {
+        int64_t d[3];
+        plan.dims(l, eps_kind, d);
+        View v;
+        v.d[0] = st.hi - st.lo;
+        v.d[1] = d[1];
+        v.d[2] = d[2];
+        v.sj = mgk::pitch_for(d[2]);
+        v.si = v.sj * d[1];
+        v.i0 = st.lo;
+        const size_t bytes = (size_t)v.d[0] * v.si * sizeof(double);
+        HIP_TRY(hipMalloc((void **)&v.p, bytes));
+        blocks.push_back(v.p);
+        HIP_TRY(hipMemsetAsync(v.p, 0, bytes, stream));
+        s->v = v;
+        return MG_OK;
+    }
+    IRange own(int l, bool eps_kind) const { return plan.own(l, eps_kind, rank); }
+
+    // plane ranges of an owned slab: the two planes next to each existing neighbour (what a halo
+    // exchange of width 2 sends) and the interior between them
+    void split(IRange o, IRange edges[2], int *n_edges, IRange *inner) const
+    {
+        const int64_t a = rank == 0 ? o.lo : o.lo + H_U, z = rank == world - 1 ? o.hi : o.hi - H_U;
+        *n_edges = 0;
+        if (a > o.lo) edges[(*n_edges)++] = IRange{o.lo, a};
+        if (z < o.hi) edges[(*n_edges)++] = IRange{z, o.hi};
+        *inner = IRange{a, z};
+    }
+
+    // One launch group of a sweep: planes r (and r2) of *alt = sweep(*u), or in place.
+    // Returns 1 when the result landed in alt, 0 when in place, < 0 on error.
+    int run_sweep(Slab &u, Slab &alt, const Slab &rhs, const Slab *fold, bool correct, const int64_t n[3], int l,
+                  IRange r, IRange r2)
+    {
+        View vu = u.v, va = alt.v;
+        const double *before = vu.p;
+        int rc;
+        if (fold) rc = mgk::prolong_smooth_rb(stream, fold->v, correct, &vu, &va, rhs.v, n, c[l], omega, 1, r, r2);
+        else rc = mgk::smooth_rb(stream, &vu, &va, rhs.v, n, c[l], omega, 1, r, r2);
+        if (rc < 0) return mgk::set_error(MG_ERR_STATE, "a two-range sweep needs the out-of-place kernel");
+        return vu.p != before ? 1 : 0;
+    }
+
+    // nu[l] red-black sweeps of a distributed level, one halo exchange after each.  With `ec`
+    // (eps of level l+1, halos current) the first sweep is preceded by the prolongation from it:
+    // u := P(ec), or u -= P(ec) when `correct` -- folded into that sweep's loads where possible.
+    int sweeps(int l, Slab *ec, bool correct)
+    {
+        int64_t n[3];
+        plan.level_n(l, n);
+        for (int sweep = 0; sweep < nu[l]; sweep++) {
+            Slab &u = l == 0 ? phi : eps[l];
+            Slab &alt = l == 0 ? phi_alt : eps_alt[l];
+            const Slab &rhs = l == 0 ? b : R[l];
+            const IRange o = own(l, l != 0);
+            const Slab *fold = nullptr;
+            if (sweep == 0 && ec) {
+                TRY(tr->finish(*ec, stream));
+                if (alt.v.p && mgk::onload_folds(u.v, correct)) {
+                    fold = ec;  // the operation rides on this sweep's loads; u stays as it is
+                } else {
+                    // applied in place once, on every stored plane this sweep reads
+                    TRY(tr->finish(u, stream));
+                    IRange pr{o.lo - H_U < u.v.i0 ? u.v.i0 : o.lo - H_U, o.hi + H_U > u.v.i_end() ? u.v.i_end() : o.hi + H_U};
+                    if (correct) mgk::prolong_correct(stream, ec->v, u.v, n, pr);
+                    else mgk::prolong(stream, ec->v, u.v, n, pr);
+                }
+            }
+            IRange edges[2], inner;
+            int n_edges;
+            split(o, edges, &n_edges, &inner);
+            const bool oop = alt.v.p && mgk::sweep_is_out_of_place(u.v);
+            const bool ovl = world > 1 && overlap && oop && inner.hi - inner.lo >= 2 * H_U;
+            TRY(tr->finish(u, stream));
+            if (ovl && l == 0 && sweep == nu[l] - 1) {
+                // The last fine sweep is followed by the residual pass, whose interior part reads no
+                // halo plane: the sweep runs as ONE launch and its exchange under that interior part
+                // (an edge launch re-reads four lead-in planes per edge).
+                const int rc = run_sweep(u, alt, rhs, fold, correct, n, l, o, IRange{0, 0});
+                if (rc < 0) return rc;
+                if (rc != 1) FAIL(MG_ERR_STATE, "out-of-place sweep expected");
+                TRY(tr->start(alt, o, H_U, stream));
+                std::swap(u, alt);
+                continue;
+            }
+            int swapped;
+            if (ovl) {
+                // edge planes need the halos of the previous sweep; the interior does not
+                int rc = run_sweep(u, alt, rhs, fold, correct, n, l, edges[0], n_edges == 2 ? edges[1] : IRange{0, 0});
+                if (rc < 0) return rc;
+                if (rc != 1) FAIL(MG_ERR_STATE, "out-of-place sweep expected");
+                TRY(tr->start(alt, o, H_U, stream));
+                rc = run_sweep(u, alt, rhs, fold, correct, n, l, inner, IRange{0, 0});
+                if (rc < 0) return rc;
+                if (rc != 1) FAIL(MG_ERR_STATE, "out-of-place sweep expected");
+                swapped = 1;
+            } else {
+                swapped = run_sweep(u, alt, rhs, fold, correct, n, l, o, IRange{0, 0});
+                if (swapped < 0) return swapped;
+            }
+            if (swapped) std::swap(u, alt);
+            if (!ovl) {
+                TRY(tr->start(u, o, H_U, stream));
+                TRY(tr->finish(u, stream));
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        return MG_OK;
+    }
+
+    // phi -= P(eps_1) of the last iteration, if it still waits for the next fine sweep
+    int flush_correction()
+    {
+        if (!correction_pending) return MG_OK;
+        // on every stored plane, halos included: eps_1's halos are current
+        TRY(tr->finish(eps[1], stream));
+        TRY(tr->finish(phi, stream));
+        mgk::prolong_correct(stream, eps[1].v, phi.v, plan.n0, plan.stored(0, false, rank, H_U));
+        HIP_TRY(hipGetLastError());
+        correction_pending = false;
+        return MG_OK;
+    }
+
+    // Steps 1)-2b) of the reference iteration (+ the restriction to level 1, which shares the
+    // pass).  Leaves the global sum of squared residuals in *d_sum.
+    int smooth_and_residual()
+    {
+        if (correction_pending && nu[0] > 0) {
+            TRY(sweeps(0, &eps[1], true));  // step 6) of the previous iteration rides along
+            correction_pending = false;
+        } else {
+            TRY(flush_correction());
+            TRY(sweeps(0, nullptr, false));
+        }
+        const IRange o = own(0, false);
+        IRange edges[2], inner, parts[3];
+        int n_edges, n_parts = 0, wait_at = 0;
+        split(o, edges, &n_edges, &inner);
+        // slab boundaries are multiples of 2^cut, so every range below starts on an even plane
+        if (world > 1 && overlap && inner.hi - inner.lo >= 2 * H_U) {
+            // the interior needs no halo plane: it runs while the last sweep's exchange completes
+            parts[n_parts++] = inner;
+            for (int e = 0; e < n_edges; e++) parts[n_parts++] = edges[e];
+            wait_at = 1;
+        } else {
+            parts[n_parts++] = o;
+        }
+        int64_t used = 0;
+        View none = phi.v;
+        none.p = nullptr;
+        for (int idx = 0; idx < n_parts; idx++) {
+            if (idx == wait_at) TRY(tr->finish(phi, stream));
+            const int64_t np = mgk::residual_restrict_partials(plan.n0, parts[idx]);
+            if (used + np > n_partials) FAIL(MG_ERR_STATE, "partial-sum buffer too small");
+            mgk::residual_restrict(stream, phi.v, b.v, none, R[1].v, plan.n0, c[0], partials + used, parts[idx]);
+            used += np;
+        }
+        mgk::sum_partials(stream, partials, used, d_sum);
+        HIP_TRY(hipGetLastError());
+        TRY(tr->finish(phi, stream));
+        return tr->allreduce(d_sum, stream);
+    }
+
+    // Levels cut..L on whole arrays (rank 0): restrict down, smooth the coarsest, (prolong,
+    // smooth) back up to level `cut`.
+    int coarse_levels()
+    {
+        int64_t n[3];
+        for (int l = cut; l < L; l++) {
+            plan.level_n(l, n);
+            mgk::restrict27(stream, cR[l].v, cR[l + 1].v, n, IRange{0, plan.planes(l + 1, false)});
+        }
+        for (int l = L; l >= cut; l--) {
+            plan.level_n(l, n);
+            if (l < L) mgk::prolong(stream, ceps[l + 1].v, ceps[l].v, n, IRange{0, n[0]});
+            View vu = ceps[l].v, va = ceps_alt[l].v;
+            const double *before = vu.p;
+            mgk::smooth_rb(stream, &vu, &va, cR[l].v, n, c[l], omega, nu[l], IRange{0, vu.d[0]});
+            if (vu.p != before) std::swap(ceps[l], ceps_alt[l]);
+        }
+        HIP_TRY(hipGetLastError());
+        return MG_OK;
+    }
+
+    // Steps 3)-5): restrict down to the cut level, gather, solve the small levels on rank 0,
+    // scatter, then (prolong, smooth) up.  Step 6), the correction of phi, is left pending for the
+    // next iteration's first sweep.
+    int coarse_correction()
+    {
+        int64_t n[3];
+        for (int l = 1; l < cut; l++) {
+            // R_l's halo plane below feeds the restriction; both feed the sweeps' red halo planes
+            TRY(tr->start(R[l], own(l, false), H_RHS, stream));
+            TRY(tr->finish(R[l], stream));
+            plan.level_n(l, n);
+            mgk::restrict27(stream, R[l].v, R[l + 1].v, n, own(l + 1, false));
+        }
+        HIP_TRY(hipGetLastError());
+        TRY(tr->gather(plan, cut, false, R[cut], rank == 0 ? &cR[cut] : nullptr, stream));
+        if (rank == 0) TRY(coarse_levels());
+        TRY(tr->scatter(plan, cut, true, rank == 0 ? &ceps[cut] : nullptr, eps[cut], H_U, stream));
+        for (int l = cut - 1; l >= 1; l--) {
+            if (nu[l] > 0) {
+                // eps_l = P(eps_{l+1}) as the first sweep's input, on halo planes too (eps_{l+1}'s
+                // halos are current), so the prolongation needs no exchange of its own
+                TRY(sweeps(l, &eps[l + 1], false));
+            } else {
+                TRY(tr->finish(eps[l + 1], stream));
+                plan.level_n(l, n);
+                mgk::prolong(stream, eps[l + 1].v, eps[l].v, n, plan.stored(l, true, rank, H_U));
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        correction_pending = true;
+        return MG_OK;
+    }
+
+    int read_sum(double *out)
+    {
+        HIP_TRY(hipMemcpyAsync(h_sum, d_sum, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        *out = *h_sum;
+        return MG_OK;
+    }
+    double l2_of(double sum) const { return std::sqrt(sum / n_nodes); }
+};
+
+namespace {
+
+int check_rank(mg_dist *d, bool need_fields)
+{
+    if (!d) FAIL(MG_ERR_INVALID, "null rank handle");
+    if (need_fields && (!d->have_rho || !d->have_phi))
+        FAIL(MG_ERR_STATE, "rho and phi planes must be set before solving");
+    HIP_TRY(hipSetDevice(d->device));
+    return MG_OK;
+}
+
+// dense planes [lo,hi) (rows of nk doubles) <-> the slab, staged through the idle twin of phi
+int upload_planes(mg_dist *d, Slab &dst, int64_t lo, int64_t hi, const double *dense, bool div_eps0)
+{
+    if (!dense || lo < dst.v.i0 || hi > dst.v.i_end() || lo >= hi)
+        FAIL(MG_ERR_INVALID, "planes [%lld,%lld) outside the stored range [%lld,%lld)", (long long)lo, (long long)hi,
+             (long long)dst.v.i0, (long long)dst.v.i_end());
+    const int64_t cap = d->phi_alt.v.d[0];  // planes the staging area holds
+    for (int64_t a = lo; a < hi; a += cap) {
+        const int64_t z = a + cap < hi ? a + cap : hi;
+        const size_t bytes = (size_t)(z - a) * dst.v.d[1] * dst.v.d[2] * sizeof(double);
+        View part = dst.v;
+        part.p = dst.plane(a);
+        part.i0 = a;
+        part.d[0] = z - a;
+        const double *src = dense + (size_t)(a - lo) * dst.v.d[1] * dst.v.d[2];
+        if (part.sj == part.d[2]) {
+            HIP_TRY(hipMemcpyAsync(part.p, src, bytes, hipMemcpyHostToDevice, d->stream));
+            if (div_eps0) mgk::div_eps0(d->stream, part);
+        } else {
+            HIP_TRY(hipMemcpyAsync(d->phi_alt.v.p, src, bytes, hipMemcpyHostToDevice, d->stream));
+            mgk::repitch_in(d->stream, part, d->phi_alt.v.p, div_eps0);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(d->stream));
+    }
+    return MG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mg_dist_unique_id(uint8_t out[MG_UNIQUE_ID_BYTES])
+{
+    if (!out) FAIL(MG_ERR_INVALID, "null argument");
+    const Rccl *api = rccl();
+    if (!api) FAIL(MG_ERR_COMM, "librccl could not be loaded");
+    ncclUniqueId id;
+    NCCL_TRY(api->GetUniqueId(&id));
+    memcpy(out, &id, MG_UNIQUE_ID_BYTES);
+    return MG_OK;
+}
+
+int mg_local_group_create(int world, int hold_back, mg_local_group **out)
+{
+    if (!out || world < 1 || world > MG_MAX_GPUS) FAIL(MG_ERR_INVALID, "bad argument");
+    mg_local_group *g = new (std::nothrow) mg_local_group();
+    if (!g) FAIL(MG_ERR_NOMEM, "host allocation failed");
+    g->world = world;
+    g->hold_back = hold_back != 0;
+    g->post.assign(world, nullptr);
+    g->value.assign(world, 0.0);
+    *out = g;
+    return MG_OK;
+}
+
+int mg_local_group_destroy(mg_local_group *g)
+{
+    delete g;
+    return MG_OK;
+}
+
+int mg_dist_destroy(mg_dist *d)
+{
+    if (!d) return MG_OK;
+    hipSetDevice(d->device);
+    if (d->stream) hipStreamSynchronize(d->stream);
+    delete d->tr;  // the RCCL transport drains its stream first
+    Slab *all[] = {&d->phi, &d->phi_alt, &d->b};
+    for (Slab *s : all)
+        if (s->done) hipEventDestroy(s->done);
+    for (int l = 0; l < MG_MAX_LEVELS; l++)
+        for (Slab *s : {&d->R[l], &d->eps[l], &d->eps_alt[l]})
+            if (s->done) hipEventDestroy(s->done);
+    for (void *p : d->blocks) hipFree(p);
+    if (d->h_sum) hipHostFree(d->h_sum);
+    if (d->ev_a) hipEventDestroy(d->ev_a);
+    if (d->ev_b) hipEventDestroy(d->ev_b);
+    if (d->stream) hipStreamDestroy(d->stream);
+    delete d;
+    return MG_OK;
+}
+
+int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
+{
+    if (!cfg || !out) FAIL(MG_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const mg_config &base = cfg->base;
+    if (cfg->world < 1 || cfg->world > MG_MAX_GPUS || cfg->rank < 0 || cfg->rank >= cfg->world)
+        FAIL(MG_ERR_INVALID, "rank %d / world %d out of range", cfg->rank, cfg->world);
+    if (base.depth < 1 || base.depth >= MG_MAX_LEVELS) FAIL(MG_ERR_INVALID, "depth %d out of range 1..%d", base.depth, MG_MAX_LEVELS - 1);
+    if (base.flags) FAIL(MG_ERR_INVALID, "a partitioned solve supports no MG_FLAG_* options");
+    for (int a = 0; a < 3; a++) {
+        if (base.n[a] < 3 || base.n[a] > 65535) FAIL(MG_ERR_INVALID, "n[%d]=%lld out of range", a, (long long)base.n[a]);
+        if (!(base.dh[a] > 0)) FAIL(MG_ERR_INVALID, "dh[%d] must be positive", a);
+    }
+    for (int l = 0; l <= base.depth; l++)
+        if (base.nu[l] < 0 || base.nu[l] > 100000) FAIL(MG_ERR_INVALID, "nu[%d]=%d out of range", l, base.nu[l]);
+    if (cfg->transport == MG_TRANSPORT_LOCAL && cfg->world > 1 && (!cfg->local_group || cfg->local_group->world != cfg->world))
+        FAIL(MG_ERR_INVALID, "the in-process transport needs an mg_local_group of the same world size");
+    if (cfg->transport != MG_TRANSPORT_LOCAL && cfg->transport != MG_TRANSPORT_RCCL) FAIL(MG_ERR_INVALID, "unknown transport %d", cfg->transport);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) FAIL(MG_ERR_NO_DEVICE, "no HIP device visible");
+    if (base.device < 0 || base.device >= count) FAIL(MG_ERR_INVALID, "device %d out of range (have %d)", base.device, count);
+    HIP_TRY(hipSetDevice(base.device));
+
+    mg_dist *d = new (std::nothrow) mg_dist();
+    if (!d) FAIL(MG_ERR_NOMEM, "host allocation failed");
+#define CREATE_TRY(expr)        \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_) {              \
+            mg_dist_destroy(d); \
+            return rc_;         \
+        }                       \
+    } while (0)
+    auto hip_ok = [](hipError_t e, const char *what) -> int {
+        if (e == hipSuccess) return MG_OK;
+        return mgk::set_error(e == hipErrorOutOfMemory ? MG_ERR_NOMEM : MG_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    };
+    d->rank = cfg->rank;
+    d->world = cfg->world;
+    d->device = base.device;
+    d->L = base.depth;
+    d->omega = base.omega;
+    d->overlap = cfg->no_overlap == 0;
+    CREATE_TRY(d->plan.init(base.n, base.depth, cfg->world, cfg->coarse_cut));
+    d->cut = d->plan.cut;
+    d->n_nodes = (double)base.n[0] * (double)base.n[1] * (double)base.n[2];
+    for (int l = 0; l <= d->L; l++) {
+        d->nu[l] = base.nu[l];
+        double k[4];
+        CREATE_TRY(mg_level_coef(base.dh, l, k));
+        d->c[l] = mgk::make_coef(k[0], k[1], k[2], k[3]);
+    }
+    CREATE_TRY(hip_ok(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), "hipStreamCreate"));
+    CREATE_TRY(hip_ok(hipEventCreate(&d->ev_a), "hipEventCreate"));
+    CREATE_TRY(hip_ok(hipEventCreate(&d->ev_b), "hipEventCreate"));
+    // the communicator first: its creation is the one step that waits for the other ranks, and a
+    // rank that failed later (out of memory, say) must not leave them waiting here
+    if (cfg->transport == MG_TRANSPORT_RCCL && cfg->world > 1) {
+        RcclTransport *t = new (std::nothrow) RcclTransport();
+        if (!t) {
+            mg_dist_destroy(d);
+            FAIL(MG_ERR_NOMEM, "host allocation failed");
+        }
+        d->tr = t;
+        CREATE_TRY(t->init(cfg->rank, cfg->world, cfg->unique_id));
+    } else {
+        LocalTransport *t = new (std::nothrow) LocalTransport();
+        if (!t) {
+            mg_dist_destroy(d);
+            FAIL(MG_ERR_NOMEM, "host allocation failed");
+        }
+        t->rank = cfg->rank;
+        t->world = cfg->world;
+        t->g = cfg->local_group;
+        d->tr = t;
+    }
+    const Plan &P = d->plan;
+    const int r = d->rank;
+    CREATE_TRY(d->alloc(&d->phi, 0, false, P.stored(0, false, r, H_U)));
+    CREATE_TRY(d->alloc(&d->phi_alt, 0, false, P.stored(0, false, r, H_U)));
+    CREATE_TRY(d->alloc(&d->b, 0, false, P.stored(0, false, r, H_RHS)));
+    for (int l = 1; l <= d->cut; l++) {
+        CREATE_TRY(d->alloc(&d->R[l], l, false, P.stored(l, false, r, H_RHS)));
+        CREATE_TRY(d->alloc(&d->eps[l], l, true, P.stored(l, true, r, H_U)));
+        if (l < d->cut) CREATE_TRY(d->alloc(&d->eps_alt[l], l, true, P.stored(l, true, r, H_U)));
+    }
+    if (r == 0)
+        for (int l = d->cut; l <= d->L; l++) {
+            CREATE_TRY(d->alloc(&d->cR[l], l, false, IRange{0, P.planes(l, false)}));
+            CREATE_TRY(d->alloc(&d->ceps[l], l, true, IRange{0, P.planes(l, true)}));
+            CREATE_TRY(d->alloc(&d->ceps_alt[l], l, true, IRange{0, P.planes(l, true)}));
+        }
+    {
+        // partial sums of the fine residual: the owned range, or interior + edges
+        const IRange o = d->own(0, false);
+        IRange edges[2], inner;
+        int n_edges;
+        d->split(o, edges, &n_edges, &inner);
+        int64_t need = mgk::residual_restrict_partials(P.n0, o);
+        int64_t parts = inner.hi > inner.lo ? mgk::residual_restrict_partials(P.n0, inner) : 0;
+        for (int e = 0; e < n_edges; e++) parts += mgk::residual_restrict_partials(P.n0, edges[e]);
+        d->n_partials = need > parts ? need : parts;
+        CREATE_TRY(hip_ok(hipMalloc((void **)&d->partials, (size_t)(d->n_partials + 1) * sizeof(double)), "hipMalloc(partials)"));
+        d->blocks.push_back(d->partials);
+        d->d_sum = d->partials + d->n_partials;
+    }
+    CREATE_TRY(hip_ok(hipHostMalloc((void **)&d->h_sum, sizeof(double), hipHostMallocDefault), "hipHostMalloc"));
+    *d->h_sum = 0;
+    CREATE_TRY(hip_ok(hipStreamSynchronize(d->stream), "hipStreamSynchronize"));
+#undef CREATE_TRY
+    *out = d;
+    return MG_OK;
+}
+
+int mg_dist_plan(mg_dist *d, int32_t *cut, int64_t own[2], int64_t stored_phi[2], int64_t stored_rho[2])
+{
+    if (!d) FAIL(MG_ERR_INVALID, "null rank handle");
+    if (cut) *cut = d->cut;
+    const IRange o = d->own(0, false);
+    if (own) { own[0] = o.lo; own[1] = o.hi; }
+    if (stored_phi) { stored_phi[0] = d->phi.v.i0; stored_phi[1] = d->phi.v.i_end(); }
+    if (stored_rho) { stored_rho[0] = d->b.v.i0; stored_rho[1] = d->b.v.i_end(); }
+    return MG_OK;
+}
+
+int mg_dist_set_rho_planes(mg_dist *d, int64_t lo, int64_t hi, const double *dense)
+{
+    TRY(check_rank(d, false));
+    TRY(upload_planes(d, d->b, lo, hi, dense, true));
+    d->have_rho = true;
+    return MG_OK;
+}
+
+int mg_dist_set_phi_planes(mg_dist *d, int64_t lo, int64_t hi, const double *dense)
+{
+    TRY(check_rank(d, false));
+    if (d->phi.pending) FAIL(MG_ERR_STATE, "a halo exchange of phi is still in flight");
+    TRY(upload_planes(d, d->phi, lo, hi, dense, false));
+    d->have_phi = true;
+    d->correction_pending = false;
+    return MG_OK;
+}
+
+int mg_dist_get_phi_planes(mg_dist *d, int64_t lo, int64_t hi, double *dense)
+{
+    TRY(check_rank(d, false));
+    if (!dense || !d->have_phi) FAIL(MG_ERR_STATE, "no phi on the device yet");
+    const IRange o = d->own(0, false);
+    if (lo < o.lo || hi > o.hi || lo >= hi) FAIL(MG_ERR_INVALID, "planes [%lld,%lld) outside the owned range [%lld,%lld)", (long long)lo, (long long)hi, (long long)o.lo, (long long)o.hi);
+    if (d->correction_pending) FAIL(MG_ERR_STATE, "a coarse-grid correction is pending: finish the solve call first");
+    TRY(d->tr->finish(d->phi, d->stream));
+    const View &v = d->phi.v;
+    const int64_t cap = d->phi_alt.v.d[0];
+    for (int64_t a = lo; a < hi; a += cap) {
+        const int64_t z = a + cap < hi ? a + cap : hi;
+        const size_t bytes = (size_t)(z - a) * v.d[1] * v.d[2] * sizeof(double);
+        View part = v;
+        part.p = d->phi.plane(a);
+        part.i0 = a;
+        part.d[0] = z - a;
+        double *dst = dense + (size_t)(a - lo) * v.d[1] * v.d[2];
+        if (part.sj == part.d[2]) {
+            HIP_TRY(hipMemcpyAsync(dst, part.p, bytes, hipMemcpyDeviceToHost, d->stream));
+        } else {
+            mgk::repitch_out(d->stream, d->phi_alt.v.p, part);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(dst, d->phi_alt.v.p, bytes, hipMemcpyDeviceToHost, d->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(d->stream));
+    }
+    return MG_OK;
+}
+
+int mg_dist_vcycles(mg_dist *d, unsigned count, double *L2)
+{
+    TRY(check_rank(d, true));
+    HIP_TRY(hipEventRecord(d->ev_a, d->stream));
+    for (unsigned it = 0; it < count; it++) {
+        TRY(d->smooth_and_residual());
+        TRY(d->coarse_correction());
+    }
+    TRY(d->flush_correction());
+    HIP_TRY(hipEventRecord(d->ev_b, d->stream));
+    double sum = 0;
+    TRY(d->read_sum(&sum));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, d->ev_a, d->ev_b));
+    d->last_ms = ms;
+    if (L2) *L2 = count ? d->l2_of(sum) : 0.0;
+    return MG_OK;
+}
+
+int mg_dist_solve(mg_dist *d, unsigned max_it, double tol, int *converged, unsigned *cycles, double *L2)
+{
+    TRY(check_rank(d, true));
+    bool conv = false;
+    double l2 = 0;
+    unsigned it = 0;
+    HIP_TRY(hipEventRecord(d->ev_a, d->stream));
+    for (it = 0; it < max_it; it++) {
+        TRY(d->smooth_and_residual());
+        double sum = 0;
+        TRY(d->read_sum(&sum));
+        l2 = d->l2_of(sum);  // the all-reduced sum: every rank takes the same decision
+        if (l2 < tol) {
+            conv = true;
+            it++;
+            break;
+        }
+        TRY(d->coarse_correction());
+    }
+    TRY(d->flush_correction());
+    HIP_TRY(hipEventRecord(d->ev_b, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, d->ev_a, d->ev_b));
+    d->last_ms = ms;
+    if (converged) *converged = conv ? 1 : 0;
+    if (cycles) *cycles = it;
+    if (L2) *L2 = l2;
+    return MG_OK;
+}
+
+int mg_dist_sync(mg_dist *d)
+{
+    TRY(check_rank(d, false));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return MG_OK;
+}
+
+int mg_dist_stats(mg_dist *d, double *last_ms, uint64_t *bytes_sent)
+{
+    if (!d) FAIL(MG_ERR_INVALID, "null rank handle");
+    if (last_ms) *last_ms = d->last_ms;
+    if (bytes_sent) *bytes_sent = d->tr ? d->tr->bytes_sent : 0;
+    return MG_OK;
+}
+
+}  // extern "C"

@@ -13,7 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmg_hip.so")
 
 MG_MAX_LEVELS = 12
-MG_ABI_VERSION = 1
+MG_ABI_VERSION = 2
+MG_MAX_GPUS = 16
+MG_UNIQUE_ID_BYTES = 128
+MG_TRANSPORT_RCCL, MG_TRANSPORT_LOCAL = 0, 1
 MG_FLAG_KEEP_FINE_RESIDUAL = 1
 MG_FLAG_RESTRICT_7PT = 2
 
@@ -28,7 +31,14 @@ _dp = C.POINTER(C.c_double)
 class MgConfig(C.Structure):
     _fields_ = [("n", C.c_int64 * 3), ("dh", C.c_double * 3), ("depth", C.c_int32),
                 ("nu", C.c_int32 * MG_MAX_LEVELS), ("omega", C.c_double),
-                ("device", C.c_int32), ("flags", C.c_int32)]
+                ("device", C.c_int32), ("flags", C.c_int32), ("n_gpus", C.c_int32),
+                ("devices", C.c_int32 * MG_MAX_GPUS), ("coarse_cut", C.c_int32)]
+
+
+class MgDistConfig(C.Structure):
+    _fields_ = [("base", MgConfig), ("rank", C.c_int32), ("world", C.c_int32), ("coarse_cut", C.c_int32),
+                ("transport", C.c_int32), ("no_overlap", C.c_int32), ("unique_id", C.c_uint8 * MG_UNIQUE_ID_BYTES),
+                ("local_group", C.c_void_p)]
 
 
 class MgTimers(C.Structure):
@@ -114,6 +124,20 @@ SYMBOLS = {
     "mg_dev_onload_folds": (C.c_int, [C.POINTER(MgDevArray), C.c_int]),
     "mg_dev_compute_ef": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.c_void_p, C.c_int64, _i64x3, _f64x3,
                                     C.c_int64, C.c_int64]),
+    # slab-partitioned solve driven inside the library, one rank per GPU
+    "mg_dist_unique_id": (C.c_int, [C.c_uint8 * MG_UNIQUE_ID_BYTES]),
+    "mg_local_group_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mg_local_group_destroy": (C.c_int, [C.c_void_p]),
+    "mg_dist_create": (C.c_int, [C.POINTER(MgDistConfig), C.POINTER(C.c_void_p)]),
+    "mg_dist_destroy": (C.c_int, [C.c_void_p]),
+    "mg_dist_plan": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int64 * 2, C.c_int64 * 2, C.c_int64 * 2]),
+    "mg_dist_set_rho_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
+    "mg_dist_set_phi_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
+    "mg_dist_get_phi_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
+    "mg_dist_vcycles": (C.c_int, [C.c_void_p, C.c_uint, _dp]),
+    "mg_dist_solve": (C.c_int, [C.c_void_p, C.c_uint, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_uint), _dp]),
+    "mg_dist_sync": (C.c_int, [C.c_void_p]),
+    "mg_dist_stats": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None
@@ -167,10 +191,20 @@ def default_config(n, dh, depth, device=0, variant_b=False):
 class Handle:
     """Owns one mg_handle (one reference MultiGridSolverVn object's worth of state)."""
 
-    def __init__(self, n, dh, depth, nu=None, omega=None, device=0, flags=0, variant_b=False):
+    def __init__(self, n, dh, depth, nu=None, omega=None, device=0, flags=0, variant_b=False, devices=None,
+                 coarse_cut=0):
+        """devices: a list of two or more GPU ordinals splits the grid into slabs over them (one host
+        thread per GPU inside the library); an ordinal may repeat (several slabs on one GPU)."""
         self.n = tuple(int(a) for a in n)
         self.depth = depth
         cfg = default_config(self.n, dh, depth, device, variant_b)
+        if devices is not None and len(devices) > 1:
+            if len(devices) > MG_MAX_GPUS:
+                raise ValueError(f"at most {MG_MAX_GPUS} devices")
+            cfg.n_gpus = len(devices)
+            for i, d in enumerate(devices):
+                cfg.devices[i] = d
+            cfg.coarse_cut = coarse_cut
         if nu is not None:
             if len(nu) != depth + 1:
                 raise ValueError("nu must have depth+1 entries")
@@ -360,3 +394,103 @@ def op_sumsq(x, device=0):
     s = C.c_double(0)
     _check(load().mg_op_sumsq(device, x.size, px, C.byref(s)))
     return s.value
+
+
+# ---- slab-partitioned solve, one rank per GPU (mg_dist_*) --------------------
+
+def dist_unique_id():
+    """128 bytes from rank 0 that every rank of an RCCL group must be created with."""
+    buf = (C.c_uint8 * MG_UNIQUE_ID_BYTES)()
+    _check(load().mg_dist_unique_id(buf))
+    return bytes(buf)
+
+
+class LocalGroup:
+    """Meeting point of ranks that are threads of this process (MG_TRANSPORT_LOCAL)."""
+
+    def __init__(self, world, hold_back=False):
+        self._g = C.c_void_p()
+        _check(load().mg_local_group_create(world, int(hold_back), C.byref(self._g)))
+
+    def close(self):
+        if getattr(self, "_g", None):
+            load().mg_local_group_destroy(self._g)
+            self._g = None
+
+    __del__ = close
+
+
+class DistRank:
+    """One rank of a slab-partitioned solve (mg_dist): construct on every rank of the group with the
+    same arguments apart from rank and device; creation, vcycles, solve and close are collective."""
+
+    def __init__(self, n, dh, depth, rank, world, device=0, unique_id=None, local_group=None, coarse_cut=0,
+                 nu=None, omega=None, overlap=True):
+        self.n = tuple(int(a) for a in n)
+        dc = MgDistConfig()
+        dc.base = default_config(self.n, dh, depth, device)
+        if nu is not None:
+            for l, v in enumerate(nu):
+                dc.base.nu[l] = v
+        if omega is not None:
+            dc.base.omega = omega
+        dc.rank, dc.world, dc.coarse_cut, dc.no_overlap = rank, world, coarse_cut, int(not overlap)
+        if local_group is not None or world == 1:
+            dc.transport = MG_TRANSPORT_LOCAL
+            dc.local_group = local_group._g if local_group is not None else None
+        else:
+            if unique_id is None or len(unique_id) != MG_UNIQUE_ID_BYTES:
+                raise ValueError("an RCCL rank needs the 128-byte unique id made on rank 0")
+            dc.transport = MG_TRANSPORT_RCCL
+            C.memmove(dc.unique_id, unique_id, MG_UNIQUE_ID_BYTES)
+        self._d = C.c_void_p()
+        _check(load().mg_dist_create(C.byref(dc), C.byref(self._d)))
+        cut = C.c_int32(0)
+        own, sp, sr = (C.c_int64 * 2)(), (C.c_int64 * 2)(), (C.c_int64 * 2)()
+        _check(load().mg_dist_plan(self._d, C.byref(cut), own, sp, sr))
+        self.cut, self.own, self.stored_phi, self.stored_rho = cut.value, tuple(own), tuple(sp), tuple(sr)
+
+    def close(self):
+        if getattr(self, "_d", None):
+            load().mg_dist_destroy(self._d)
+            self._d = None
+
+    def _planes(self, f, rng, of_planes, chunk):
+        lo, hi = rng
+        for a in range(lo, hi, chunk):
+            z = min(a + chunk, hi)
+            arr, p = _in(of_planes(a, z))
+            Handle._shape(arr, (z - a,) + self.n[1:], "planes")
+            _check(f(self._d, a, z, p))
+
+    def set_rho(self, rho_of_planes, chunk=32):
+        """rho_of_planes(lo, hi) -> dense array of global planes [lo,hi); called for a few planes at a
+        time, so a rank never holds its whole slab in host memory."""
+        self._planes(load().mg_dist_set_rho_planes, self.stored_rho, rho_of_planes, chunk)
+
+    def set_phi(self, phi_of_planes, chunk=32):
+        self._planes(load().mg_dist_set_phi_planes, self.stored_phi, phi_of_planes, chunk)
+
+    def get_phi_owned(self):
+        lo, hi = self.own
+        out = np.empty((hi - lo,) + self.n[1:])
+        _check(load().mg_dist_get_phi_planes(self._d, lo, hi, _out(out)))
+        return lo, out
+
+    def vcycles(self, count=1):
+        l2 = C.c_double(0)
+        _check(load().mg_dist_vcycles(self._d, count, C.byref(l2)))
+        return l2.value
+
+    def solve(self, max_it=10000, tol=1e-4):
+        conv, cyc, l2 = C.c_int(0), C.c_uint(0), C.c_double(0)
+        _check(load().mg_dist_solve(self._d, max_it, tol, C.byref(conv), C.byref(cyc), C.byref(l2)))
+        return bool(conv.value), cyc.value, l2.value
+
+    def sync(self):
+        _check(load().mg_dist_sync(self._d))
+
+    def stats(self):
+        ms, sent = C.c_double(0), C.c_uint64(0)
+        _check(load().mg_dist_stats(self._d, C.byref(ms), C.byref(sent)))
+        return {"last_ms": ms.value, "bytes_sent": int(sent.value)}
