@@ -227,8 +227,188 @@ def run_single(args):
     print(json.dumps(out))
 
 
+def sweep_roofline(libmg, n, planes, device):
+    """HIP-event time of the dominant kernel on a slab of this rank's shape: one full red-black sweep
+    (out of place) of `planes` owned planes of n x n nodes, launched on torch's current stream and
+    timed with events on that stream.  Compulsory bytes: read u 8 + rhs 8 + write u 8 = 24 B/pt."""
+    import ctypes as C
+    import torch
+    from multigrid_amd import problem
+    pitch = (n + 1) & ~1
+    dev = torch.device("cuda", device)
+    u = torch.zeros((planes + 4, n, pitch), dtype=torch.float64, device=dev)
+    alt = torch.zeros_like(u)
+    rhs = torch.zeros((planes + 2, n, pitch), dtype=torch.float64, device=dev)
+    lib = libmg.load()
+    N = (n, n, n)
+    coef = (C.c_double * 4)()
+    libmg._check(lib.mg_level_coef((C.c_double * 3)(*problem.main_extents_dh(N)), 0, coef))
+    # the slab sits in the middle of the grid: global planes [n/2 - 2, n/2 + planes + 2)
+    i0 = max(2, n // 2 - planes // 2)
+    arr = lambda t, first: libmg.MgDevArray(t.data_ptr(), t.shape[0], n, n, first)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    flag = C.c_int(0)
+
+    def launch():
+        libmg._check(lib.mg_dev_smooth_rb(stream, C.byref(arr(u, i0 - 2)), C.byref(arr(alt, i0 - 2)),
+                                          C.byref(arr(rhs, i0 - 1)), (C.c_int64 * 3)(*N), coef, 1.4, 1,
+                                          i0, i0 + planes, 0, 0, C.byref(flag)))
+    launch()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    reps = 5
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(reps):
+        launch()
+    ev[1].record()
+    torch.cuda.synchronize()
+    us = ev[0].elapsed_time(ev[1]) * 1e3 / reps
+    nbytes = 24.0 * planes * n * n
+    return {"bound": "hbm", "kernel": "smooth_fine (one full red-black sweep of this rank's slab)",
+            "achieved": nbytes / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_us": us,
+            "bytes_per_launch": nbytes,
+            "operator_equivalent": {"bytes_per_launch": nbytes * 32.0 / 24.0,
+                                    "GBps": nbytes * 32.0 / 24.0 / (us * 1e-6) / 1e9,
+                                    "note": "bytes of the two colour passes this launch replaces"}}
+
+
 def run_distributed(args):
-    """N > 1: one rank per GPU (launched by torch.distributed.run), 1025^3 slab-partitioned."""
+    """N > 1: one rank per GPU (launched by torch.distributed.run), 1025^3 slab-partitioned, driven by
+    the C++ rank driver inside libmg_hip (mg_dist_*): halo planes, the norm all-reduce and the coarse
+    gather/scatter go over RCCL.  torch.distributed (gloo) only carries the rendezvous: the RCCL
+    unique id, the barriers around the timed region and the max over the ranks' times."""
+    import torch  # before libmg_hip: both must share one HIP runtime
+    import torch.distributed as dist
+    import numpy as np
+    from multigrid_amd import libmg, problem
+
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    world = int(os.environ["WORLD_SIZE"])
+    # RCCL prints a version banner on stdout at communicator creation; keep stdout for the one
+    # JSON line by pointing fd 1 at stderr until the result is ready
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    torch.cuda.set_device(local)
+    dist.init_process_group("gloo")
+    libmg.load()
+    n = args.size or 1025
+    N = (n, n, n)
+    depth = args.depth or problem.reference_depth_for(N)
+    dh = problem.main_extents_dh(N)
+
+    def make_rank():
+        ids = [libmg.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        d = libmg.DistRank(N, dh, depth, rank, world, device=local, unique_id=ids[0])
+        d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
+        d.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
+        return d
+
+    d = make_rank()
+
+    def fence():
+        d.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup:
+        d.vcycles(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    l2 = d.vcycles(args.steps)   # K iterations enqueued back to back; returns after this rank's stream drained
+    fence()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    wall = float(dt.item())
+    vps = args.steps / wall
+    npts = float(n) ** 3
+    stats = d.stats()
+    cut, own = d.cut, d.own
+
+    solve = None
+    if not args.no_solve:
+        d.close()
+        d = make_rank()
+        fence()
+        t0 = time.perf_counter()
+        ok, cycles, l2s = d.solve(10000, args.tol)
+        fence()
+        solve = {"tol": args.tol, "converged": ok, "cycles": cycles, "seconds": time.perf_counter() - t0, "L2": l2s}
+    d.close()
+    dist.barrier()
+
+    roofline = sweep_roofline(libmg, n, own[1] - own[0], local)
+    base1 = None
+    if rank == 0 and not args.no_single_gpu_compare and n <= 1025:
+        torch.cuda.empty_cache()
+        h = libmg.Handle(N, dh, depth, device=local)
+        h.set_rho(problem.synthetic_rho(N))
+        h.set_phi(np.zeros(N))
+        h.vcycles(2)
+        t0 = time.perf_counter()
+        k = max(3, min(args.steps, 10))
+        h.vcycles(k)
+        t1 = (time.perf_counter() - t0) / k
+        h.close()
+        base1 = {"workload": f"{n}^3 V{depth} on one GPU of this node, same run", "ms_per_step": t1 * 1e3,
+                 "vcycles_per_s": 1.0 / t1, "gdof_per_s": npts / t1 / 1e9, "speedup": vps * t1}
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        # the reference-order CPU cycle on one host core of this node, after the group is gone (the
+        # other ranks have nothing left to wait for): one iteration at this workload's size
+        cpu = cpu_baseline(n, depth, max(1, min(args.cpu_cycles, 1 if n > 513 else 3))) if args.cpu_cycles > 0 else None
+        out = {"metric": "GDoF/s", "value": npts * vps / 1e9, "unit": "GDoF/s (fine-grid unknowns x V-cycles/s / 1e9)",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"{n}^3 fp64 multigrid V{depth} cycle, red-black GS-SOR, slab-partitioned over "
+                                      f"{world} GPUs (halo planes over RCCL send/recv, levels >= {cut} "
+                                      f"gathered on rank 0)", "grid": n, "depth": depth, "driver": "libmg_hip mg_dist (C++)",
+                          "note": "N=1 runs the 513^3 headline configuration; N>=2 run 1025^3 (strong scaling among N>=2)"},
+               "vcycles_per_s": vps, "last_L2": l2, "roofline": roofline, "cpu_baseline": cpu, "solve": solve,
+               "single_gpu_same_workload": base1, "halo_bytes_sent_rank0": stats["bytes_sent"],
+               "device_ms_per_step_rank0": stats["last_ms"] / args.steps}
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+
+
+def run_shared_gpu_rehearsal(args):
+    """MG_BENCH_SHARE_GPU=1 python bench.py --gpus N on a box with ONE GPU: the N ranks are host
+    threads inside the library and every slab lives on GPU 0 (mg_create with n_gpus = N; halo planes
+    by device-to-device copies).  It rehearses the partitioned code path; its numbers say nothing
+    about a multi-GPU node."""
+    import numpy as np
+    from multigrid_amd import libmg, problem
+    libmg.load()
+    n = args.size or 513
+    N = (n, n, n)
+    depth = args.depth or problem.reference_depth_for(N)
+    h = libmg.Handle(N, problem.main_extents_dh(N), depth, devices=[0] * args.gpus)
+    h.set_rho(problem.synthetic_rho(N))
+    h.set_phi(np.zeros(N))
+    if args.warmup:
+        h.vcycles(args.warmup)
+    t0 = time.perf_counter()
+    l2 = h.vcycles(args.steps)
+    wall = time.perf_counter() - t0
+    print(json.dumps({"metric": "GDoF/s", "value": float(n) ** 3 * args.steps / wall / 1e9, "unit": "GDoF/s",
+                      "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+                      "vs_baseline": None, "dtype": "f64", "data": "synthetic", "last_L2": l2,
+                      "config": {"workload": f"REHEARSAL: {n}^3 V{depth} as {args.gpus} slabs sharing ONE GPU "
+                                             f"(in-process transport); not a multi-GPU measurement"}}))
+    h.close()
+
+
+def run_distributed_python(args):
+    """The same N > 1 run with the Python orchestration (multigrid_amd/dist.py over
+    torch.distributed point-to-point ops) instead of the C++ rank driver: MG_BENCH_DRIVER=python."""
     import torch  # before libmg_hip: both must share one HIP runtime
     import torch.distributed as dist
     import numpy as np
@@ -389,10 +569,16 @@ def main():
         run_single(args)
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if os.environ.get("MG_BENCH_SHARE_GPU") and os.environ.get("MG_BENCH_DRIVER") != "python":
+            run_shared_gpu_rehearsal(args)
+            return
         raise SystemExit(spawn_ranks(args.gpus))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}")
-    run_distributed(args)
+    if os.environ.get("MG_BENCH_DRIVER") == "python":
+        run_distributed_python(args)
+    else:
+        run_distributed(args)
 
 
 if __name__ == "__main__":

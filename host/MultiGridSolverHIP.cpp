@@ -66,12 +66,31 @@ const double *MultiGridSolverHIP::pack(Field &f)
 MultiGridSolverHIP::MultiGridSolverHIP(World &w, int max_it, double tol, int depth, int device, bool variant_b)
     : PotentialSolver(w), max_solver_it(max_it), tolerance(tol)
 {
+    init(depth, device, variant_b, {}, 0);
+}
+
+MultiGridSolverHIP::MultiGridSolverHIP(World &w, int max_it, double tol, int depth, const std::vector<int> &devices,
+                                       int coarse_cut)
+    : PotentialSolver(w), max_solver_it(max_it), tolerance(tol)
+{
+    if (devices.empty() || devices.size() > MG_MAX_GPUS) throw std::runtime_error("MultiGridSolverHIP: 1..16 devices");
+    init(depth, devices[0], false, devices, coarse_cut);
+}
+
+void MultiGridSolverHIP::init(int depth, int device, bool variant_b, const std::vector<int> &devices, int coarse_cut)
+{
     mg_config cfg;
     double3 dh = world.getDh();
     const double h[3] = {dh[0], dh[1], dh[2]};
     if (variant_b) check(mg_default_config_b(&cfg, world.ni, world.nj, world.nk, h, depth), "mg_default_config_b");
     else check(mg_default_config(&cfg, world.ni, world.nj, world.nk, h, depth), "mg_default_config");
     cfg.device = device;
+    if (devices.size() > 1) {
+        multi_gpu = true;
+        cfg.n_gpus = int(devices.size());
+        for (std::size_t g = 0; g < devices.size(); g++) cfg.devices[g] = devices[g];
+        cfg.coarse_cut = coarse_cut;
+    }
     check(mg_create(&cfg, &handle), "mg_create");
     // Page-lock the fields in place where they are one block (failure only costs copy speed, e.g.
     // when another solver on the same World has locked them already); otherwise stage through a
@@ -177,6 +196,10 @@ int GaussSeidelSolverHIP::iterate(int *converged)
 // there when world.phi still is that potential, after an upload otherwise.
 void MultiGridSolverHIP::computeEF()
 {
+    if (multi_gpu) {  // the slabs hold phi; the field is differentiated on the host copy
+        PotentialSolver::computeEF();
+        return;
+    }
     try {
         upload_phi_if_stale();
         check(mg_compute_ef(handle), "mg_compute_ef");

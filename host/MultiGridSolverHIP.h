@@ -49,6 +49,12 @@ public:
     // variant_b: the reference's "B" classes (cpp/PotentialSolver.h:274-350): 7-point restriction,
     // and for depth 5 the sweep schedule 1,2,3,4,5,50
     MultiGridSolverHIP(World &world, int max_it, double tol, int depth, int device = 0, bool variant_b = false);
+    // The grid split into slabs of i-planes over several GPUs (one host thread per GPU inside the
+    // library, halo planes over RCCL; an ordinal may repeat, e.g. {0, 0}: two slabs on one GPU).
+    // coarse_cut: first level solved whole on devices[0] (0 = the first with <= 128 planes).
+    // computeEF() of such a solver is the host loop on the downloaded potential.
+    MultiGridSolverHIP(World &world, int max_it, double tol, int depth, const std::vector<int> &devices,
+                       int coarse_cut = 0);
     ~MultiGridSolverHIP() override;
     MultiGridSolverHIP(const MultiGridSolverHIP &) = delete;
     MultiGridSolverHIP &operator=(const MultiGridSolverHIP &) = delete;
@@ -78,7 +84,9 @@ protected:
     double last_l2 = 0;
 
 private:
+    void init(int depth, int device, bool variant_b, const std::vector<int> &devices, int coarse_cut);
     const double *pack(Field &f);
+    bool multi_gpu = false;
     bool device_phi_current();
     void remember_phi();
     void upload_phi_if_stale();

@@ -7,6 +7,7 @@
 //   box_mg [n=41] [depth=2] [tol=1e-4] [--b] [--dump file] [--dump-ef file]
 //   --b selects the reference's "B" solver variant (7-point restriction);
 //   --vti file writes phi, rho and ef as VTK ImageData in the reference's ASCII format
+//   --gpus 0,1,2,3 splits the grid into slabs over those GPUs (an ordinal may repeat);
 //   --pageable keeps the World's fields in ordinary memory (default: page-locked blocks);
 //   --again repeats solve() twice more: once with world.phi untouched (the device copy is reused),
 //   once after the driver has reset world.phi to zero (noticed, uploaded again);
@@ -19,6 +20,7 @@
 #include <cstring>
 #include <exception>
 #include <iostream>
+#include <vector>
 
 #include "../include/mg_hip.h"
 #include "MultiGridSolverHIP.h"
@@ -42,6 +44,7 @@ int main(int argc, char **argv)
     double tol = 1e-4;
     const char *dump = nullptr, *dump_ef = nullptr, *vti = nullptr;
     bool variant_b = false, again = false, pageable = false;
+    std::vector<int> gpus;
     int pos = 0;
     for (int a = 1; a < argc; a++) {
         if (!strcmp(argv[a], "--dump") && a + 1 < argc) dump = argv[++a];
@@ -49,6 +52,9 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--b")) variant_b = true;
         else if (!strcmp(argv[a], "--again")) again = true;
         else if (!strcmp(argv[a], "--pageable")) pageable = true;
+        else if (!strcmp(argv[a], "--gpus") && a + 1 < argc) {
+            for (char *t = strtok(argv[++a], ","); t; t = strtok(nullptr, ",")) gpus.push_back(atoi(t));
+        }
         else if (!strcmp(argv[a], "--vti") && a + 1 < argc) vti = argv[++a];
         else if (pos == 0) { n = atoi(argv[a]); pos++; }
         else if (pos == 1) { depth = atoi(argv[a]); pos++; }
@@ -74,8 +80,9 @@ int main(int argc, char **argv)
                                          (std::sin(pi * x) * std::sin(pi * y) * std::sin(pi * z) +
                                           0.5 * std::sin(5 * pi * x) * std::sin(3 * pi * y) * std::sin(7 * pi * z));
                 }
-        MultiGridSolverHIP *mg = depth == 0 ? new GaussSeidelSolverHIP(world, 100000, tol)
-                                            : new MultiGridSolverHIP(world, 10000, tol, depth, 0, variant_b);
+        MultiGridSolverHIP *mg = depth == 0       ? new GaussSeidelSolverHIP(world, 100000, tol)
+                                 : gpus.size() > 1 ? new MultiGridSolverHIP(world, 10000, tol, depth, gpus)
+                                                   : new MultiGridSolverHIP(world, 10000, tol, depth, 0, variant_b);
         PotentialSolver *solver = mg;  // used through the base pointer, like the reference driver
         auto t0 = std::chrono::high_resolution_clock::now();
         const bool ok = solver->solve();

@@ -167,3 +167,20 @@ def test_driver_writes_vti_of_the_solution(box, gpu, orc, tmp_path):
     assert np.allclose(got.transpose(2, 1, 0), phi, rtol=1e-5, atol=1e-12)  # 6 significant digits in the file
     ef = np.array(arrays["ef"][1]).reshape(n, n, n, 3).transpose(2, 1, 0, 3)
     assert np.allclose(ef, orc.compute_ef(phi, orc.main_extents_dh((n, n, n))), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_multi_gpu_solver_behind_the_same_interface(box, gpu, tmp_path):
+    """MultiGridSolverHIP(world, max_it, tol, depth, {0, 0, 0}): three slabs (here all on GPU 0) behind
+    PotentialSolver::solve() give the single-GPU solver's potential bit for bit; computeEF() falls
+    back to the host loop on the downloaded potential and agrees too."""
+    outs = []
+    for extra in ([], ["--gpus", "0,0,0"]):
+        phi, ef = tmp_path / f"phi{len(extra)}.bin", tmp_path / f"ef{len(extra)}.bin"
+        p = subprocess.run([BOX, "129", "3", "1e-6", "--dump", str(phi), "--dump-ef", str(ef)] + extra,
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        outs.append((np.fromfile(phi), np.fromfile(ef), [l for l in p.stdout.splitlines() if "converged=" in l][0].split()[:2]))
+    assert outs[0][2] == outs[1][2]
+    assert_bit_equal(outs[1][0], outs[0][0], "phi from three slabs")
+    assert_bit_equal(outs[1][1], outs[0][1], "E from the host loop")
