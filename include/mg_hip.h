@@ -116,6 +116,11 @@ int mg_abi_version(void);
 const char *mg_last_error(void);
 /* Number of visible HIP devices (0 when there is none; never fails). */
 int mg_device_count(void);
+/* Division by the stencil diagonal (cpp/PotentialSolver.cpp:3783): by default the kernels form the
+ * correctly rounded quotient from the reciprocal with two FMA corrections; on != 0 makes every
+ * solver object and operator call created from now on use the division instruction instead.
+ * Both give the reference's bits; the switch exists so that tests can hold one against the other. */
+int mg_set_exact_division(int on);
 
 /* ---- solver object: replaces `new MultiGridSolverVn(world, max_it, tol)` and
  * its members R_h, R_2h.., eps_h, eps_2h.. (cpp/PotentialSolver.h:188-270,

@@ -445,6 +445,12 @@ int mg_abi_version(void) { return MG_ABI_VERSION; }
 
 const char *mg_last_error(void) { return g_err; }
 
+int mg_set_exact_division(int on)
+{
+    mgk::set_exact_division(on != 0);
+    return MG_OK;
+}
+
 int mg_device_count(void)
 {
     int count = 0;
@@ -509,7 +515,6 @@ int mg_create(const mg_config *cfg, mg_handle **out)
     h->restrict7 = (cfg->flags & MG_FLAG_RESTRICT_7PT) != 0;
     // the fused residual+restriction kernel implements the 27-point weights only
     h->fused_residual = L >= 1 && !(cfg->flags & MG_FLAG_KEEP_FINE_RESIDUAL) && !h->restrict7;
-    if (getenv("MG_KEEP_RF")) h->fused_residual = false;  // A/B measurements
     memset(&h->timers, 0, sizeof(h->timers));
     memset(h->lv, 0, sizeof(h->lv));
 #define CREATE_TRY(expr)          \

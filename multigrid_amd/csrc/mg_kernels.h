@@ -72,7 +72,6 @@ struct WgOrder {
     }
 #endif
 };
-// MG_WG_ORDER=plain|blocked overrides the default (A/B runs).
 bool wg_order_blocked();
 
 // Row pitch used for every device array: rows start 16-byte aligned.
@@ -86,6 +85,8 @@ struct Coef {
 };
 // Fills rd / fma_div from d.
 Coef make_coef(double cx, double cy, double cz, double d);
+// on: coefficients made from now on divide with the division instruction (fma_div = 0).
+void set_exact_division(bool on);
 
 #if defined(__HIPCC__)
 // x / c.d, correctly rounded (bit-identical to the IEEE division the reference performs,

@@ -8,7 +8,7 @@
 // march inside the kernel) covers i.
 #include "mg_kernels.h"
 
-#include <cstdlib>
+#include <atomic>
 #include <cstring>
 
 namespace mgk {
@@ -323,6 +323,11 @@ __global__ __launch_bounds__(256) void k_correct(double *__restrict__ phi,
 
 }  // namespace
 
+// mg_set_exact_division(): every quotient by the division instruction (see div_d)
+std::atomic<bool> g_exact_division{false};
+
+void set_exact_division(bool on) { g_exact_division.store(on, std::memory_order_relaxed); }
+
 Coef make_coef(double cx, double cy, double cz, double d)
 {
     Coef c;
@@ -337,8 +342,7 @@ Coef make_coef(double cx, double cy, double cz, double d)
     memcpy(&bits, &d, sizeof(bits));
     const uint64_t frac = bits & 0xFFFFFFFFFFFFFull;
     const int expo = (int)((bits >> 52) & 0x7FF);
-    static const bool exact_div = getenv("MG_EXACT_DIV") != nullptr;  // A/B: force true division
-    c.fma_div = (!exact_div && d > 0 && expo > 923 && expo < 1123 && frac != 0xFFFFFFFFFFFFFull) ? 1 : 0;
+    c.fma_div = (!g_exact_division.load(std::memory_order_relaxed) && d > 0 && expo > 923 && expo < 1123 && frac != 0xFFFFFFFFFFFFFull) ? 1 : 0;
     return c;
 }
 
@@ -392,32 +396,13 @@ void smooth_colour(hipStream_t s, View u, View rhs, const int64_t n[3], Coef c, 
 }
 
 // Kernel choice for the smoother: the fused single-pass sweep pays once the level
-// no longer fits the caches; tiny levels are launch-latency bound either way.
-// MG_SMOOTH=simple|fused overrides (for A/B measurements).
-static bool use_fused_sweep(const View &u)
-{
-    static const int forced = [] {
-        const char *e = getenv("MG_SMOOTH");
-        if (!e) return 0;
-        if (!strcmp(e, "simple")) return 1;
-        if (!strcmp(e, "fused")) return 2;
-        return 0;
-    }();
-    if (forced == 1) return false;
-    if (forced == 2) return true;
-    static const int min_dim = [] { const char *e = getenv("MG_FUSED_MIN"); return e ? atoi(e) : 128; }();
-    return u.d[0] >= 4 && u.d[1] >= min_dim && u.d[2] >= min_dim;
-}
+// no longer fits the caches; tiny levels are launch-latency bound either way (measured: with
+// the threshold at 64 rows the 513^3 cycle is 1 % slower).
+static bool use_fused_sweep(const View &u) { return u.d[0] >= 4 && u.d[1] >= 128 && u.d[2] >= 128; }
 
-bool wg_order_blocked()
-{
-    static const int mode = [] {
-        const char *e = getenv("MG_WG_ORDER");
-        if (e && !strcmp(e, "plain")) return 0;
-        return 1;
-    }();
-    return mode == 1;
-}
+// The marching kernels number their workgroups XCD-blocked (WgOrder); plain order cost the 513^3
+// fine sweep 18 % more read traffic.
+bool wg_order_blocked() { return true; }
 
 bool sweep_is_out_of_place(const View &u) { return use_fused_sweep(u); }
 
@@ -435,8 +420,6 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
     const size_t lds_bytes = sizeof(double) * smooth_lds_doubles(u->d[0], u->d[1], u->d[2]);
     const int64_t per_colour = (n[0] - 2) * (n[1] - 2) * ((n[2] - 1) / 2);
     static const bool lds_ok = [] {
-        const char *e = getenv("MG_SMOOTH_LDS");
-        if (e && !strcmp(e, "0")) return false;
         return hipFuncSetAttribute((const void *)k_smooth_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    kLdsSmoothMaxBytes) == hipSuccess &&
                hipFuncSetAttribute((const void *)k_smooth_lds<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -476,11 +459,10 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
 
 bool onload_folds(const View &u, bool correct)
 {
-    static const bool allow = getenv("MG_NO_ONLOAD") == nullptr;  // A/B: force separate launches
     // On-load prolongation pays on big levels only (measured at 129^3: 35 us fused against
     // 23 + 5 us separate; at 257^3: 125 against 107 + 27); the fine-grid correction always pays.
     const bool big = correct || (u.d[1] >= 256 && u.d[2] >= 256);
-    return allow && big && use_fused_sweep(u);
+    return big && use_fused_sweep(u);
 }
 
 int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, View rhs,

@@ -17,7 +17,6 @@
 // the 27 restriction terms are added left to right with the first index fastest.
 #include "mg_kernels.h"
 
-#include <cstdlib>
 
 namespace mgk {
 
@@ -269,13 +268,8 @@ struct Geometry {
 };
 
 // window rows: 32 (256 threads) or 64 (512 threads; fewer halo rows re-read per owned row, pays
-// once a plane has enough windows to fill the chip).  MG_RR_WJ=32|64 overrides (A/B runs).
-int window_rows(const int64_t n[3])
-{
-    static const int wj = [] { const char *e = getenv("MG_RR_WJ"); return e ? atoi(e) : 0; }();
-    if (wj == 32 || wj == 64) return wj;
-    return n[1] >= 256 ? 64 : 32;
-}
+// once a plane has enough windows to fill the chip).
+int window_rows(const int64_t n[3]) { return n[1] >= 256 ? 64 : 32; }
 
 Geometry geometry(const int64_t n[3], IRange r)
 {
@@ -287,8 +281,6 @@ Geometry geometry(const int64_t n[3], IRange r)
     const bool blocked = wg_order_blocked();
     int nchunks = pick_chunks((int64_t)g.tiles_j * g.tiles_k, planes, 3, 2, window_rows(n) == 64 ? 256 : 512,
                               !blocked);
-    static const int want = [] { const char *e = getenv("MG_RR_CHUNKS"); return e ? atoi(e) : 0; }();
-    if (want > 0) nchunks = want;
     int CI = (int)((planes + nchunks - 1) / nchunks);
     CI += CI & 1;  // chunks start on even planes: a coarse plane's three fine planes stay together
     g.nchunks = nchunks;

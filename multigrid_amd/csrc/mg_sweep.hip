@@ -22,7 +22,6 @@
 // expression is the same (no contraction, true division).
 #include "mg_kernels.h"
 
-#include <cstdlib>
 
 namespace mgk {
 
@@ -374,19 +373,12 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
 
 }  // namespace
 
-static int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 template <int WJ, int NT, int D = 2>
 static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec, int load_op,
                            const int64_t n[3], Coef c, double omega, IRange r, IRange r2)
 {
     constexpr int WKP = 32;
     constexpr int TJ = WJ - 4, TK = 2 * WKP - 4;
-    static const int want_chunks = env_int("MG_SWEEP_CHUNKS", 0);  // tuning knob (A/B runs)
     const int64_t planes = r.hi - r.lo;
     if (planes <= 0) return;
     const int tiles_j = (int)((uin.d[1] + TJ - 1) / TJ);
@@ -394,7 +386,6 @@ static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec
     const int tiles = tiles_j * tiles_k;
     const bool blocked = wg_order_blocked();
     int nchunks = pick_chunks(tiles, planes, 4, 1, WJ == 32 ? 512 : 256, !blocked);
-    if (want_chunks > 0) nchunks = want_chunks;
     int CI = (int)((planes + nchunks - 1) / nchunks);
     int cstride = CI, rhi = (int)r.hi;
     if (r2.hi > r2.lo) {
@@ -424,10 +415,9 @@ static void launch_sweep(hipStream_t s, View uin, View uout, View rhs, View ec, 
                          const int64_t n[3], Coef c, double omega, IRange r, IRange r2)
 {
     // 64-row windows (512 threads) re-read fewer halo rows per owned row; they pay once a plane has
-    // enough windows to fill the chip.  MG_SWEEP_WJ=32|64 and MG_SWEEP_WJ64_MIN=<rows> override (A/B runs).
-    static const int forced = env_int("MG_SWEEP_WJ", 0);
-    static const int min64 = env_int("MG_SWEEP_WJ64_MIN", 256);
-    const int wj = (forced == 32 || forced == 64) ? forced : (uin.d[1] >= min64 ? 64 : 32);
+    // enough windows to fill the chip (measured: level with 257 rows the same either way, 513 rows
+    // 0.69 against 0.86 ms)
+    const int wj = uin.d[1] >= 256 ? 64 : 32;
     // Measured at 513^3 and not built any more: 1024 threads per window and prefetch depths 1 and 3
     // (the latter at 256 VGPRs) were slower than or level with 512 threads at depth 2.
     if (wj == 64) launch_sweep_t<64, 512>(s, uin, uout, rhs, ec, load_op, n, c, omega, r, r2);

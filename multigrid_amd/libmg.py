@@ -65,6 +65,7 @@ SYMBOLS = {
     "mg_abi_version": (C.c_int, []),
     "mg_last_error": (C.c_char_p, []),
     "mg_device_count": (C.c_int, []),
+    "mg_set_exact_division": (C.c_int, [C.c_int]),
     "mg_default_config": (C.c_int, [C.POINTER(MgConfig), C.c_int64, C.c_int64, C.c_int64, _f64x3, C.c_int]),
     "mg_default_config_b": (C.c_int, [C.POINTER(MgConfig), C.c_int64, C.c_int64, C.c_int64, _f64x3, C.c_int]),
     "mg_create": (C.c_int, [C.POINTER(MgConfig), C.POINTER(_H)]),
@@ -143,12 +144,36 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm ships its own copy of the HIP runtime (same soname as the system's).  A process
+    that ends up with both copies initialised finds no device in the second one.  If torch is
+    installed but not imported yet, map ITS copy first: libmg_hip.so then binds to it, and a later
+    `import torch` finds its runtime already loaded -- one runtime whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # torch's runtime is already mapped
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for loc in (spec.submodule_search_locations if spec and spec.submodule_search_locations else []):
+        path = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass  # fall back to the system runtime
+            return
+
+
 def load():
     """Load libmg_hip.so and bind every declared symbol; raises if it is missing."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise MgError(-100, f"{LIB_PATH} not built (run python -m multigrid_amd.build)")
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(lib, name)  # AttributeError if the export is missing

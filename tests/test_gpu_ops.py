@@ -151,3 +151,37 @@ def test_sumsq(gpu, orc, count):
 def test_sumsq_is_deterministic(gpu):
     x = phi_like((129 ** 3,), rng(9))
     assert gpu.op_sumsq(x) == gpu.op_sumsq(x)
+
+
+@pytest.fixture
+def exact_division(gpu):
+    """Every quotient by the division instruction for the duration of a test."""
+    gpu.load().mg_set_exact_division(1)
+    yield
+    gpu.load().mg_set_exact_division(0)
+
+
+def test_division_instruction_and_reciprocal_form_agree(gpu, orc, exact_division):
+    """The kernels divide by the stencil diagonal through a correctly rounded reciprocal form; with
+    mg_set_exact_division(1) they use the division instruction.  Both must give the oracle's bits:
+    the sweep kernels of every size class (one workgroup in LDS, colour launches, the single-pass
+    marching kernel), the field kernel, and whole cycles."""
+    g = rng(21)
+    for shape, sweeps in (((17, 17, 17), 50), ((41, 41, 41), 3), ((129, 129, 129), 2)):
+        u, rho = phi_like(shape, g), rho_like(shape, g)
+        c = orc.coeffs(dh_for(shape), 0)
+        want = orc.smooth(u.copy(), rho, shape, c, 1.4, sweeps, div_eps0=True, rb=True)
+        assert_bit_equal(gpu.op_smooth_rb(u.copy(), rho, shape, c, 1.4, sweeps, rhs_is_rho=True), want,
+                         f"sweep {shape} with the division instruction")
+    phi = phi_like((33, 21, 45), g)
+    assert_bit_equal(gpu.op_compute_ef(phi, dh_for(phi.shape)), orc.compute_ef(phi, dh_for(phi.shape)), "E")
+    N = (65, 65, 65)
+    dh = orc.main_extents_dh(N)
+    rho = orc.synthetic_rho(N)
+    want = np.zeros(N)
+    orc.Solver(N, dh, 3).solve(want, rho, 3, 0.0, rb=True)
+    with gpu.Handle(N, dh, 3) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        h.vcycles(3)
+        assert_bit_equal(h.get_phi(), want, "three cycles with the division instruction")

@@ -8,6 +8,6 @@ import json
 d=json.load(open('/tmp/ab.json'))
 print("ms/step %.3f  vps %.1f  GDoF/s %.1f"%(d["ms_per_step"],d["vcycles_per_s"],d["value"]))
 for k,v in d["kernels"].items():
-    print("  %-16s n=%5d avg_us=%9.1f GB/s=%8.1f share=%.3f"%(k,v["launches"],v["avg_us"],v["GBps"],v["share"]))
+    print("  %-16s n=%5d avg_us=%9.1f opeq GB/s=%8.1f share=%.3f"%(k,v["launches"],v["avg_us"],v["operator_equivalent_GBps"],v["share"]))
 PY
 done
