@@ -212,6 +212,32 @@ def run_single(args):
     extras["host_transfers"] = {"seconds": dt, "GBps": 3 * 8.0 * npts / dt / 1e9,
                                 "what": "mg_set_rho + mg_set_phi + mg_get_phi, pageable host arrays"}
     del buf
+    # What one solve() of the host adapter moves when the World's fields live in page-locked blocks
+    # (mg_host_alloc; host/box_mg does so) and phi is still current on the device: rho up, phi down.
+    import ctypes as C
+    lib = libmg.load()
+    blocks = []
+    try:
+        for _ in range(2):
+            ptr = C.c_void_p()
+            libmg._check(lib.mg_host_alloc(C.byref(ptr), int(npts) * 8))
+            blocks.append(ptr)
+        pin = [np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_double)), shape=N) for b in blocks]
+        pin[0][...] = rho
+        h.set_rho(pin[0])
+        t0 = time.perf_counter()
+        h.set_rho(pin[0])
+        h.get_phi(pin[1])
+        dt = time.perf_counter() - t0
+        extras["host_transfers_pinned"] = {"seconds": dt, "GBps": 2 * 8.0 * npts / dt / 1e9,
+                                           "what": "mg_set_rho + mg_get_phi, page-locked host arrays (per-solve "
+                                                   "traffic of the host adapter once phi is resident)"}
+        if solve:
+            extras["solve_wall_including_transfers_s"] = solve["seconds"] + dt
+        del pin
+    finally:
+        for b in blocks:
+            lib.mg_host_free(b)
     h.close()
 
     cpu = cpu_baseline(n, depth, args.cpu_cycles) if args.cpu_cycles > 0 else None
