@@ -197,13 +197,24 @@ def run_single(args):
     # read u 8 + rhs 8 + write u 8 = 24 B/pt, HIP events around each launch
     h.set_profiling(True)
     h.reset_timers()
-    h.gs_solve(12, 0.0)
+    for _ in range(6):
+        h.gs_solve(1, 0.0)  # one sweep (and one norm) per call
     t = h.timers()["smooth_fine"]
-    h.set_profiling(False)
     if t["launches"]:
         us = 1e3 * t["ms"] / t["launches"]
         extras["plain_sweep"] = {"avg_us": us, "GBps": 24.0 * npts / (us * 1e-6) / 1e9,
                                  "frac_of_hbm_peak": 24.0 * npts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        # two sweeps per launch (what the Gauss-Seidel solver and levels with several sweeps run):
+        # 25 sweeps = one single launch + 12 paired ones; 2 x 12 B/pt per sweep
+        h.reset_timers()
+        h.gs_solve(25, 0.0)
+        t2 = h.timers()["smooth_fine"]
+        if t2["launches"] == 13:
+            us2 = (1e3 * t2["ms"] - us) / 12.0
+            extras["paired_sweeps"] = {"avg_us_per_launch": us2, "GBps": 24.0 * npts / (us2 * 1e-6) / 1e9,
+                                       "frac_of_hbm_peak": 24.0 * npts / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                       "what": "two red-black sweeps in one pass: read u 8 + rhs 8 + write u 8 B/pt per launch"}
+    h.set_profiling(False)
     t0 = time.perf_counter()
     h.set_rho(rho)
     h.set_phi(np.zeros(N))

@@ -744,12 +744,18 @@ int mg_gs_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsig
     unsigned it = 0;
     h->have_ef = false;
     HIP_TRY(hipEventRecord(h->ev_a, h->stream));
+    // The reference sweeps once per iteration and tests the residual when it % 25 == 0
+    // (cpp/PotentialSolver.cpp:268).  The sweeps up to the next test are issued as one batch (the
+    // sweep kernels then take them two per launch); `it` is the last iteration of the batch.
     for (it = 0; it < max_it; it++) {
+        unsigned batch = it % 25 == 0 ? 1 : 25 - it % 25 + 1;  // through the next iteration with it % 25 == 0
+        if (batch > max_it - it) batch = max_it - it;
         {
-            Prof p(h, MG_T_SMOOTH_FINE, 32.0 * N);
-            p.launches = mgk::smooth_rb(h->stream, &h->phi, &h->phi_alt, h->b, f.n, f.c, h->cfg.omega, 1, all);
+            Prof p(h, MG_T_SMOOTH_FINE, 32.0 * N * batch);
+            p.launches = mgk::smooth_rb(h->stream, &h->phi, &h->phi_alt, h->b, f.n, f.c, h->cfg.omega, (int)batch, all);
         }
-        if (it % 25 == 0) {  // cpp/PotentialSolver.cpp:268
+        it += batch - 1;
+        if (it % 25 == 0) {
             {
                 Prof p(h, MG_T_RESIDUAL, 16.0 * N);
                 mgk::gs_residual_sumsq(h->stream, h->phi, h->b, f.n, f.c, h->partials, all);

@@ -110,6 +110,28 @@ __device__ __forceinline__ double div_d(double x, const Coef &c)
     return fma(fma(-q1, c.d, x), c.rd, q1);
 }
 
+// div_d() for N numerators at once: the reciprocal form runs unconditionally on all of them
+// (straight-line code the N chains interleave in) and the rare numerator outside its range is
+// redone with the division instruction behind ONE branch, instead of a branch per quotient.
+template <int N>
+__device__ __forceinline__ void div_d_n(const double (&x)[N], const Coef &c, double (&g)[N])
+{
+    constexpr uint32_t kLo = (1023u - 800u) << 20, kSpan = 1600u << 20;
+    bool redo = !c.fma_div;
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        const double q0 = x[n] * c.rd;
+        const double q1 = fma(fma(-q0, c.d, x[n]), c.rd, q0);
+        g[n] = fma(fma(-q1, c.d, x[n]), c.rd, q1);
+        redo |= ((uint32_t)__double2hiint(x[n]) & 0x7fffffffu) - kLo >= kSpan;
+    }
+    if (redo) {
+#pragma unroll
+        for (int n = 0; n < N; n++)
+            if (!c.fma_div || ((uint32_t)__double2hiint(x[n]) & 0x7fffffffu) - kLo >= kSpan) g[n] = x[n] / c.d;
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -149,6 +171,10 @@ void smooth_colour(hipStream_t s, View u, View rhs, const int64_t n[3], Coef c, 
 // A non-empty r2 (same length as r, disjoint, above it) is swept in the same launch.
 void sweep_rb_fused(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c,
                     double omega, IRange r, IRange r2 = IRange{0, 0});
+// Two full sweeps in one pass (half the traffic per sweep): planes r of u_out = sweep(sweep(u_in)).
+// u_in must hold planes [r.lo-4, r.hi+4) and rhs planes [r.lo-3, r.hi+3) as far as they exist.
+void sweep_rb_fused2(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c,
+                     double omega, IRange r);
 // The same with the operation that precedes the sweep applied to u_in as it is loaded:
 // correct: u_in := u_in - P(ec) (fine grid, phi -= eps_h); otherwise u_in := P(ec) over
 // 0..n-2 (a coarse level's prolongated initial guess).  ec = eps of the next coarser level.

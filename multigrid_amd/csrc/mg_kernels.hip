@@ -435,8 +435,22 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
         return 1;
     }
     const bool fused = alt && alt->p && use_fused_sweep(*u);
+    // two sweeps per launch where the stored planes reach four beyond the range (always, for a
+    // whole array; a slab with two halo planes exchanges between sweeps instead)
+    const auto holds = [&](const View &v, int64_t lo, int64_t hi, int64_t top) {
+        return v.i0 <= (lo < 0 ? 0 : lo) && v.i_end() >= (hi > top ? top : hi);
+    };
+    const bool pairs = fused && !pair && holds(*u, r.lo - 4, r.hi + 4, n[0]) && holds(rhs, r.lo - 3, r.hi + 3, n[0] - 1);
+    int launches = 0;
     for (int sw = 0; sw < sweeps; sw++) {
-        if (fused) {
+        launches++;
+        if (pairs && sw + 1 < sweeps) {
+            sweep_rb_fused2(s, *u, *alt, rhs, n, c, omega, r);
+            View t = *u;
+            *u = *alt;
+            *alt = t;
+            sw++;
+        } else if (fused) {
             sweep_rb_fused(s, *u, *alt, rhs, n, c, omega, r, r2);
             View t = *u;
             *u = *alt;
@@ -452,9 +466,10 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
             if (red.hi > u->i_end() - 1) red.hi = u->i_end() - 1;
             smooth_colour(s, *u, rhs, n, c, omega, 0, red);
             smooth_colour(s, *u, rhs, n, c, omega, 1, r);
+            launches++;
         }
     }
-    return fused ? sweeps : 2 * sweeps;
+    return launches;
 }
 
 bool onload_folds(const View &u, bool correct)

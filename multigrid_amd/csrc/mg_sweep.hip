@@ -21,6 +21,7 @@
 // exactly the operand values of the sequential colour order, and the update
 // expression is the same (no contraction, true division).
 #include "mg_kernels.h"
+#include <cstdlib>
 
 
 namespace mgk {
@@ -73,19 +74,24 @@ __device__ __forceinline__ void red_phase_impl(double *P, d2 (&v0)[Q], const d2 
     }
 }
 
-template <int E, int Q, int ROWSTEP, int WK>
-__device__ __forceinline__ void black_phase_impl(const double *P, d2 (&vm1)[Q], const d2 (&vm2)[Q],
+// okmask: bit E * Q + q = the point may be updated in this phase (the caller shifts its phase's
+// bits down).  PUBLISH: the new values also go to the plane's LDS slot, for a later phase of the
+// same march that reads this plane's finished values.
+template <int E, int Q, int ROWSTEP, int WK, bool PUBLISH = false>
+__device__ __forceinline__ void black_phase_impl(double *P, d2 (&vm1)[Q], const d2 (&vm2)[Q],
                                                  const d2 (&v0)[Q], const d2 (&bm1)[Q], unsigned okmask,
                                                  const Coef &c, double omega)
 {
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        const double *Y = P + q * ROWSTEP + E;
+        double *Y = P + q * ROWSTEP + E;
         const double uc = elem<E>(vm1[q]);
         const double g = div_d(elem<E>(bm1[q]) + c.cx * (elem<E>(vm2[q]) + elem<E>(v0[q])) +
                                c.cy * (Y[-WK] + Y[WK]) + c.cz * (Y[-1] + Y[1]), c);
-        const bool ok = (okmask >> ((2 + E) * Q + q)) & 1u;
-        elem<E>(vm1[q]) = ok ? uc + omega * (g - uc) : uc;
+        const bool ok = (okmask >> (E * Q + q)) & 1u;
+        const double un = ok ? uc + omega * (g - uc) : uc;
+        elem<E>(vm1[q]) = un;
+        if (PUBLISH) Y[0] = un;
     }
 }
 
@@ -340,9 +346,9 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
         if (pb >= ia && pb < ib) {
             if (pb >= 1 && pb <= nI - 2) {
                 // black of plane p-1 sits where red of plane p does
-                const double *Y = &lds[((pb + 3) % 3) * PL + tbase];
-                if (e1) black_phase_impl<1, Q, RPP * WK, WK>(Y, vm1, vm2, v0, bm1, okmask, c, omega);
-                else black_phase_impl<0, Q, RPP * WK, WK>(Y, vm1, vm2, v0, bm1, okmask, c, omega);
+                double *Y = &lds[((pb + 3) % 3) * PL + tbase];
+                if (e1) black_phase_impl<1, Q, RPP * WK, WK>(Y, vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
+                else black_phase_impl<0, Q, RPP * WK, WK>(Y, vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) {
@@ -371,7 +377,264 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
     }
 }
 
+// Value of lane - 1 / lane + 1 of the wave (lanes 0 / 63, which have no such neighbour, get 0).
+__device__ __forceinline__ double lane_left(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_right(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// One colour phase on a plane whose LDS slot keeps the two pair elements apart: element e of
+// (row r, pair m) at e * HALF + (r + 1) * WKP + m.  The j-1 / j+1 neighbours of a point are the
+// same element one row up / down (consecutive lanes read consecutive words: no bank conflicts);
+// of the k-1 / k+1 neighbours one is the lane's other pair element and one the adjacent lane's,
+// fetched by a wave shift (at the ends of a 32-lane row it comes from another row: window-edge
+// columns, never used).  P points at element 0 of (row rw - 1, pair m), the row above the
+// lane's first one, so every access is P plus a non-negative constant; vc is the plane being
+// updated, va / vb its i-1 / i+1 neighbours, all as the lane's registers hold them.
+// okmask: bit E * Q + q = the point may be updated.  PUBLISH: new values also go to the slot.
+template <int E, int Q, int ROWSTEP, int WKP, int HALF, bool PUBLISH>
+__device__ __forceinline__ void phase_split(double *P, d2 (&vc)[Q], const d2 (&va)[Q], const d2 (&vb)[Q],
+                                            const d2 (&b)[Q], unsigned okmask, const Coef &c, double omega)
+{
+    double x[Q], g[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const double *X = P + E * HALF + q * ROWSTEP;
+        const double mate = elem<1 - E>(vc[q]);
+        const double far = E ? lane_right(mate) : lane_left(mate);
+        x[q] = elem<E>(b[q]) + c.cx * (elem<E>(va[q]) + elem<E>(vb[q])) + c.cy * (X[0] + X[2 * WKP]) +
+               c.cz * (E ? mate + far : far + mate);
+    }
+    div_d_n<Q>(x, c, g);
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const double uc = elem<E>(vc[q]);
+        const bool ok = (okmask >> (E * Q + q)) & 1u;
+        const double un = ok ? uc + omega * (g[q] - uc) : uc;
+        elem<E>(vc[q]) = un;
+        if (PUBLISH) P[E * HALF + q * ROWSTEP + WKP] = un;
+    }
+}
+
+// TWO full red-black sweeps in one pass over the arrays (12 bytes per point and sweep instead
+// of 24): the second sweep follows the first two planes behind.  Iteration p of the march does
+//   sweep 1: red of plane p, black of plane p-1      (as k_sweep_rb)
+//   sweep 2: red of plane p-2, black of plane p-3, store plane p-3
+// Plane p-1 is finished for sweep 1 after its black update, which is all the red update of plane
+// p-2 in sweep 2 waits for; every point sees exactly the operand values of two sweeps run one
+// after the other, so the result is bit-identical to two launches of k_sweep_rb.
+//
+// Five LDS slots hold planes p-3 .. p+1.  Each phase reads, from other lanes, only values
+// written in an earlier iteration (one barrier per iteration) and writes only positions of the
+// colour nobody reads in that phase: red positions of slot p, black of slot p-1 (read by sweep 2
+// an iteration later), red of slot p-2; the black update of plane p-3 goes to registers and out.
+// Outputs are the window minus four rings.
+template <int WJ, int WKP, int D, int NT>
+__global__ __launch_bounds__(NT) void k_sweep_rb2(View uin, View uout, View rhs, int nI, int nJ, int nK,
+                                                   Coef c, double omega, int CI, int nchunks, int tiles_k,
+                                                   int rlo, int rhi, WgOrder order)
+{
+    constexpr int WK = 2 * WKP;
+    constexpr int TJ = WJ - 8, TK = WK - 8;
+    constexpr int RPP = NT / WKP;
+    constexpr int Q = WJ / RPP;
+    static_assert(WJ % RPP == 0, "window rows must be a multiple of rows per pass");
+    static_assert(RPP % 4 == 0 && TJ % 2 == 0, "row parity must be the same for all rows of a wave");
+    static_assert(8 * Q <= 32, "update mask has 8 bits per owned row");
+    static_assert(WKP == 32, "the wave shifts assume 32 lanes per row");
+    constexpr int HALF = (WJ + 2) * WKP;  // one pair element of a plane, with a guard row above and below
+    constexpr int PL = 2 * HALF;
+    constexpr int NS = 5;
+    constexpr int RS = RPP * WKP;         // from owned row q to q + 1
+    __shared__ double lds[NS * PL];
+
+    const int tid = threadIdx.x;
+    const int m = tid % WKP, rr = tid / WKP;
+    const int rw = (rr >> 1) + (RPP / 2) * (rr & 1);
+    const int tbase = rw * WKP + m;  // element 0 of (row rw - 1, pair m) in a slot
+    const int item = order.item(blockIdx.x);
+    if (item < 0) return;
+    const int ntiles = order.total / nchunks;
+    const int chunk = order.blocked ? item / ntiles : item % nchunks;
+    const int tile = order.blocked ? item % ntiles : item / nchunks;
+    const int tk = tile % tiles_k, tj = tile / tiles_k;
+    const int j0 = tj * TJ - 4, k0 = tk * TK - 4;
+    const int uJ = (int)uin.d[1], uK = (int)uin.d[2];
+    const int rJ = (int)rhs.d[1], rK = (int)rhs.d[2];
+    const int ulo = (int)uin.i0, uhi = (int)uin.i_end() - 1;
+    const int blo = (int)rhs.i0, bhi = (int)rhs.i_end() - 1;
+    const int ia = rlo + chunk * CI;
+    const int ib = min(ia + CI, rhi);
+    if (ia >= ib) return;
+    const int kk = k0 + 2 * m;
+    const int kku = min(max(kk, 0), (uK - 1) & ~1);
+    const int kkr = min(max(kk, 0), (rK - 1) & ~1);
+    auto load_u = [&](int i, int q) -> d2 {
+        const int j = min(max(j0 + q * RPP + rw, 0), uJ - 1);
+        const int ic = min(max(i, ulo), uhi);
+        return *reinterpret_cast<const d2 *>(uin.p + uin.at(ic, j, kku));
+    };
+    auto load_b = [&](int i, int q) -> d2 {
+        const int j = min(max(j0 + q * RPP + rw, 0), rJ - 1);
+        const int ic = min(max(i, blo), bhi);
+        return *reinterpret_cast<const d2 *>(rhs.p + rhs.at(ic, j, kkr));
+    };
+    // slot of plane p - back, given sp = slot of plane p (kept as a small loop-carried index: the
+    // slot offset then folds into the LDS instructions' immediate offsets)
+    int sp = (ia + 2 * NS - 3) % NS;
+    auto slot = [&](int back) -> double * {
+        int t = sp - back;
+        t = t < 0 ? t + NS : (t >= NS ? t - NS : t);
+        return lds + (unsigned)(t * PL + tbase);
+    };
+
+    // u planes p-4 .. p+1 and D in flight; right-hand side of planes p-3 .. p and D in flight
+    d2 vm4[Q], vm3[Q], vm2[Q], vm1[Q], v0[Q], vp1[Q], vf[D][Q], bm3[Q], bm2[Q], bm1[Q], b0[Q], bf[D][Q];
+    const int p0 = ia - 3;  // first plane whose red update (sweep 1) the outputs depend on
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        vm4[q] = vm3[q] = vm2[q] = d2{0.0, 0.0};
+        bm3[q] = bm2[q] = bm1[q] = d2{0.0, 0.0};
+        vm1[q] = load_u(p0 - 1, q);
+        v0[q] = load_u(p0, q);
+        vp1[q] = load_u(p0 + 1, q);
+        b0[q] = load_b(p0, q);
+#pragma unroll
+        for (int d = 0; d + 1 < D; d++) {
+            vf[d][q] = load_u(p0 + 2 + d, q);
+            bf[d][q] = load_b(p0 + 1 + d, q);
+        }
+    }
+    auto fill = [&](int back, const d2 (&v)[Q]) {
+        double *S = slot(back);
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            S[WKP + q * RS] = v[q].x;
+            S[WKP + HALF + q * RS] = v[q].y;
+        }
+    };
+    fill(0, v0);
+
+    // bit (ph * 2 + E) * Q + q: the point of phase ph (0: red 1, 1: black 1, 2: red 2, 3: black 2),
+    // pair element E, owned row q is an interior point of the level
+    unsigned okmask = 0;
+#pragma unroll
+    for (int ph = 0; ph < 4; ph++)
+#pragma unroll
+        for (int E = 0; E < 2; E++)
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int r = q * RPP + rw, j = j0 + r, col = 2 * m + E, k = k0 + col;
+                const bool ok = j >= 1 && j <= nJ - 2 && k >= 1 && k <= nK - 2 && r >= 1 + ph && r <= WJ - 2 - ph &&
+                                col >= 1 + ph && col <= WK - 2 - ph;
+                okmask |= (ok ? 1u : 0u) << ((ph * 2 + E) * Q + q);
+            }
+
+    const int plast = ib + 2;  // black of sweep 2 reaches plane ib-1 at p = ib+2
+    for (int p = p0; p <= plast; p++) {
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            vf[D - 1][q] = load_u(min(p + 1 + D, plast + 1), q);
+            bf[D - 1][q] = load_b(min(p + D, plast), q);
+        }
+        __syncthreads();
+        // which element of this lane's pairs is red in plane p (wave-uniform, see k_sweep_rb); the
+        // same element is black in plane p-1, red in p-2, black in p-3
+        const bool e1 = __builtin_amdgcn_readfirstlane((p + j0 + rw) & 1) != 0;
+        if (p >= 1 && p <= nI - 2) {
+            if (e1) phase_split<1, Q, RS, WKP, HALF, true>(slot(0), v0, vm1, vp1, b0, okmask, c, omega);
+            else phase_split<0, Q, RS, WKP, HALF, true>(slot(0), v0, vm1, vp1, b0, okmask, c, omega);
+        }
+        const int pb = p - 1;
+        if (pb >= p0 + 1 && pb >= 1 && pb <= nI - 2) {
+            if (e1) phase_split<1, Q, RS, WKP, HALF, true>(slot(1), vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
+            else phase_split<0, Q, RS, WKP, HALF, true>(slot(1), vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
+        }
+        const int pr = p - 2;
+        if (pr >= p0 + 2 && pr >= 1 && pr <= nI - 2) {
+            if (e1) phase_split<1, Q, RS, WKP, HALF, true>(slot(2), vm2, vm3, vm1, bm2, okmask >> (4 * Q), c, omega);
+            else phase_split<0, Q, RS, WKP, HALF, true>(slot(2), vm2, vm3, vm1, bm2, okmask >> (4 * Q), c, omega);
+        }
+        const int pk = p - 3;
+        if (pk >= ia) {
+            if (pk >= 1 && pk <= nI - 2) {
+                if (e1) phase_split<1, Q, RS, WKP, HALF, false>(slot(3), vm3, vm4, vm2, bm3, okmask >> (6 * Q), c, omega);
+                else phase_split<0, Q, RS, WKP, HALF, false>(slot(3), vm3, vm4, vm2, bm3, okmask >> (6 * Q), c, omega);
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int r = q * RPP + rw;
+                const int j = j0 + r;
+                if (r >= 4 && r <= WJ - 5 && m >= 2 && m <= WKP - 3 && j < uJ && kk < uK)
+                    *reinterpret_cast<d2 *>(uout.p + uout.at(pk, j, kk)) = vm3[q];
+            }
+        }
+        fill(-1, vp1);
+        sp = sp + 1 == NS ? 0 : sp + 1;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            vm4[q] = vm3[q];
+            vm3[q] = vm2[q];
+            vm2[q] = vm1[q];
+            vm1[q] = v0[q];
+            v0[q] = vp1[q];
+            vp1[q] = vf[0][q];
+            bm3[q] = bm2[q];
+            bm2[q] = bm1[q];
+            bm1[q] = b0[q];
+            b0[q] = bf[0][q];
+#pragma unroll
+            for (int d = 0; d + 1 < D; d++) {
+                vf[d][q] = vf[d + 1][q];
+                bf[d][q] = bf[d + 1][q];
+            }
+        }
+    }
+}
+
 }  // namespace
+
+// Two sweeps in one launch (k_sweep_rb2).  u_in must hold planes [r.lo-4, r.hi+4) as far as they
+// exist in the level.
+template <int WJ, int NT, int D = 2>
+static void launch_sweep2_t(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c, double omega,
+                            IRange r)
+{
+    constexpr int WKP = 32;
+    constexpr int TJ = WJ - 8, TK = 2 * WKP - 8;
+    const int64_t planes = r.hi - r.lo;
+    if (planes <= 0) return;
+    const int tiles_j = (int)((uin.d[1] + TJ - 1) / TJ);
+    const int tiles_k = (int)((uin.d[2] + TK - 1) / TK);
+    const int tiles = tiles_j * tiles_k;
+    const int nchunks = pick_chunks(tiles, planes, 8, 1, 256, false);
+    const int CI = (int)((planes + nchunks - 1) / nchunks);
+    const WgOrder order{nchunks * tiles, 1};
+    hipLaunchKernelGGL((k_sweep_rb2<WJ, WKP, D, NT>), dim3(order.grid()), dim3(NT), 0, s, uin, uout, rhs, (int)n[0],
+                       (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k, (int)r.lo, (int)r.hi, order);
+}
+
+void sweep_rb_fused2(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c, double omega,
+                     IRange r)
+{
+    static const int cfg = getenv("MG_RB2_CFG") ? atoi(getenv("MG_RB2_CFG")) : 0;
+    if (cfg == 1) launch_sweep2_t<48, 768, 3>(s, uin, uout, rhs, n, c, omega, r);
+    else if (cfg == 2) launch_sweep2_t<32, 512, 2>(s, uin, uout, rhs, n, c, omega, r);
+    else if (cfg == 3) launch_sweep2_t<32, 512, 3>(s, uin, uout, rhs, n, c, omega, r);
+    else if (cfg == 4) launch_sweep2_t<48, 384, 2>(s, uin, uout, rhs, n, c, omega, r);
+    else if (cfg == 5) launch_sweep2_t<32, 256, 2>(s, uin, uout, rhs, n, c, omega, r);
+    else launch_sweep2_t<48, 768>(s, uin, uout, rhs, n, c, omega, r);
+}
 
 template <int WJ, int NT, int D = 2>
 static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec, int load_op,

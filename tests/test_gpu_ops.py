@@ -142,6 +142,27 @@ def test_smooth_rb_coarse_form(gpu, orc, n, sweeps):
     assert_bit_equal(got, want, "smooth_rb coarse")
 
 
+@pytest.mark.parametrize("shape,sweeps", [((129, 129, 129), 2), ((130, 131, 135), 4), ((128, 168, 184), 5),
+                                          ((9, 128, 128), 2), ((131, 209, 129), 3), ((257, 257, 257), 5)],
+                         ids=str)
+def test_smooth_rb_two_sweeps_per_launch(gpu, orc, shape, sweeps):
+    """From 128 nodes per row on, sweeps run in pairs inside one launch (the second sweep two
+    planes behind the first); window and chunk edges fall at different places for each shape."""
+    g = rng(61)
+    n = tuple(a - 1 for a in shape)  # coarse form: the array is one node larger than the level
+    e, R = phi_like(shape, g), phi_like(n, g)
+    c = orc.coeffs(dh_for(tuple(2 * a + 1 for a in n)), 1)
+    want = orc.smooth(e.copy(), R, n, c, 1.4, sweeps, div_eps0=False, rb=True)
+    got = gpu.op_smooth_rb(e.copy(), R, n, c, 1.4, sweeps, rhs_is_rho=False)
+    assert_bit_equal(got, want, "paired sweeps, coarse form")
+    if shape[0] <= 131:
+        u, rho = phi_like(shape, g), rho_like(shape, g)
+        c = orc.coeffs(dh_for(shape), 0)
+        want = orc.smooth(u.copy(), rho, shape, c, 1.4, sweeps, div_eps0=True, rb=True)
+        got = gpu.op_smooth_rb(u.copy(), rho, shape, c, 1.4, sweeps, rhs_is_rho=True)
+        assert_bit_equal(got, want, "paired sweeps, fine form")
+
+
 @pytest.mark.parametrize("count", [1, 7, 4096, 41 ** 3, 129 ** 3])
 def test_sumsq(gpu, orc, count):
     x = phi_like((count,), rng(8))
