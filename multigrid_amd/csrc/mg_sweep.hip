@@ -21,6 +21,7 @@
 // exactly the operand values of the sequential colour order, and the update
 // expression is the same (no contraction, true division).
 #include "mg_kernels.h"
+#include <type_traits>
 
 
 namespace mgk {
@@ -497,7 +498,12 @@ __global__ __launch_bounds__(NT) void k_sweep_rb2(View uin, View uout, View rhs,
         return lds + (unsigned)(t * PL + tbase);
     };
 
-    // u planes p-4 .. p+1 and D in flight; right-hand side of planes p-3 .. p and D in flight
+    // u planes p-4 .. p+1 and D requested ahead; right-hand side of planes p-3 .. p and D ahead.
+    // The requested planes land in D buffers used in turn (the loop is unrolled D times so that
+    // each iteration names its buffers statically): a register with a load in flight is not
+    // touched until the iteration that needs its plane.  Passing in-flight values down a chain of
+    // register copies would make every copy wait for its load at the end of the iteration that
+    // issued it, which serialises the memory latency with the arithmetic.
     d2 vm4[Q], vm3[Q], vm2[Q], vm1[Q], v0[Q], vp1[Q], vf[D][Q], bm3[Q], bm2[Q], bm1[Q], b0[Q], bf[D][Q];
     const int p0 = ia - 3;  // first plane whose red update (sweep 1) the outputs depend on
 #pragma unroll
@@ -508,10 +514,11 @@ __global__ __launch_bounds__(NT) void k_sweep_rb2(View uin, View uout, View rhs,
         v0[q] = load_u(p0, q);
         vp1[q] = load_u(p0 + 1, q);
         b0[q] = load_b(p0, q);
+        // iteration p0 + d takes plane p0 + d + 2 (right-hand side p0 + d + 1) from buffer (d + 1) % D
 #pragma unroll
         for (int d = 0; d + 1 < D; d++) {
-            vf[d][q] = load_u(p0 + 2 + d, q);
-            bf[d][q] = load_b(p0 + 1 + d, q);
+            vf[(d + 1) % D][q] = load_u(p0 + 2 + d, q);
+            bf[(d + 1) % D][q] = load_b(p0 + 1 + d, q);
         }
     }
     auto fill = [&](int back, const d2 (&v)[Q]) {
@@ -540,11 +547,14 @@ __global__ __launch_bounds__(NT) void k_sweep_rb2(View uin, View uout, View rhs,
             }
 
     const int plast = ib + 2;  // black of sweep 2 reaches plane ib-1 at p = ib+2
-    for (int p = p0; p <= plast; p++) {
+    // One plane step.  K = (p - p0) % D: the buffer this step's requests go to; its plane p+2
+    // (right-hand side p+1) waits in buffer (K + 1) % D.
+    auto step = [&](int p, auto kc) {
+        constexpr int K = decltype(kc)::value, KU = (K + 1) % D;
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            vf[D - 1][q] = load_u(min(p + 1 + D, plast + 1), q);
-            bf[D - 1][q] = load_b(min(p + D, plast), q);
+            vf[K][q] = load_u(min(p + 1 + D, plast + 1), q);
+            bf[K][q] = load_b(min(p + D, plast), q);
         }
         __syncthreads();
         // which element of this lane's pairs is red in plane p (wave-uniform, see k_sweep_rb); the
@@ -587,17 +597,20 @@ __global__ __launch_bounds__(NT) void k_sweep_rb2(View uin, View uout, View rhs,
             vm2[q] = vm1[q];
             vm1[q] = v0[q];
             v0[q] = vp1[q];
-            vp1[q] = vf[0][q];
+            vp1[q] = vf[KU][q];
             bm3[q] = bm2[q];
             bm2[q] = bm1[q];
             bm1[q] = b0[q];
-            b0[q] = bf[0][q];
-#pragma unroll
-            for (int d = 0; d + 1 < D; d++) {
-                vf[d][q] = vf[d + 1][q];
-                bf[d][q] = bf[d + 1][q];
-            }
+            b0[q] = bf[KU][q];
         }
+    };
+    for (int p = p0; p <= plast; p += D) {
+        step(p, std::integral_constant<int, 0>{});
+        if constexpr (D > 1)
+            if (p + 1 <= plast) step(p + 1, std::integral_constant<int, 1 % D>{});
+        if constexpr (D > 2)
+            if (p + 2 <= plast) step(p + 2, std::integral_constant<int, 2 % D>{});
+        static_assert(D <= 3, "the plane loop is unrolled for up to three buffers");
     }
 }
 
