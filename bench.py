@@ -35,8 +35,10 @@ KERNEL_BYTES_PER_POINT = {"smooth_fine": 16.0, "residual": 24.0, "restrict": 9.0
                           "smooth_coarse": 16.0, "prolong": 9.0, "prolong_correct": 17.0}
 
 
-PROFILE_KERNEL = {"smooth_fine": "k_sweep_rb", "residual": "k_residual_restrict",
-                  "prolong_correct": "k_prolong<true>", "smooth_coarse": "k_sweep_rb"}
+# kernel names in the profile summaries: (prefix, suffix).  The fine sweep of the timed cycle is the
+# single-pass kernel in its "correction applied while loading" form (last template argument 1).
+PROFILE_KERNEL = {"smooth_fine": ("k_sweep_rb<", ", 1>"), "residual": ("k_residual_restrict", ""),
+                  "prolong_correct": ("k_prolong<true>", "")}
 
 
 def profiled_traffic(kind):
@@ -46,13 +48,13 @@ def profiled_traffic(kind):
     bench.py cannot run the profiler around itself; None when no summary is present."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")))
-    prefix = PROFILE_KERNEL.get(kind)
-    if not files or not prefix:
+    match = PROFILE_KERNEL.get(kind)
+    if not files or not match:
         return None, None
     try:
         prof = json.load(open(files[-1]))
-        best = max((v.get("hbm_bytes_max_launch", 0.0) for k, v in prof["kernels"].items() if k.startswith(prefix)),
-                   default=0.0)
+        best = max((v.get("hbm_bytes_max_launch", 0.0) for k, v in prof["kernels"].items()
+                    if k.startswith(match[0]) and k.endswith(match[1])), default=0.0)
         return (best or None), os.path.basename(files[-1])
     except Exception:
         return None, None

@@ -6,7 +6,7 @@ launches, the coarse tail on rank 0) with a communicator that moves nothing: hal
 their initial zeros, so the numbers mean nothing, the kernels and their launch geometry are the
 real ones.  What is missing from these times is only what the transport adds on a multi-GPU node.
 
-    python tools/slab_rank_time.py [--size 1025] [--cases 8:3,8:0,4:1,2:0]
+    python tools/slab_rank_time.py [--size 1025] [--cases 8:3,8:0,4:1,2:0] [--cut 4]
 """
 import argparse
 import os
@@ -46,10 +46,10 @@ class SoloComm(mgd.Comm):
             slab.rows(lo, hi).copy_(full.rows(lo, hi))
 
 
-def measure(n, world, rank, cycles=10, overlap=True):
+def measure(n, world, rank, cycles=10, overlap=True, cut=None):
     N = (n, n, n)
     depth = problem.reference_depth_for(N)
-    s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, mgd.HipOps(0), SoloComm(rank, world), overlap=overlap)
+    s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, mgd.HipOps(0), SoloComm(rank, world), overlap=overlap, cut=cut)
     s.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
     s.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
     marks = []
@@ -104,11 +104,12 @@ def main():
     ap.add_argument("--size", type=int, default=1025)
     ap.add_argument("--cases", default="8:3,8:0,4:1,2:0")
     ap.add_argument("--no-overlap", action="store_true", help="whole-slab launches, no edge/interior split")
+    ap.add_argument("--cut", type=int, default=None, help="first level solved whole on rank 0 (default: first with <= 128 planes)")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     for case in args.cases.split(","):
         w, r = (int(x) for x in case.split(":"))
-        res = measure(args.size, w, r, overlap=not args.no_overlap)
+        res = measure(args.size, w, r, overlap=not args.no_overlap, cut=args.cut)
         print(" ".join(f"{k}={v:.3f}" if isinstance(v, float) else f"{k}={v}" for k, v in res.items()), flush=True)
 
 
