@@ -17,6 +17,8 @@
 // the 27 restriction terms are added left to right with the first index fastest.
 #include "mg_kernels.h"
 
+#include <type_traits>
+
 
 namespace mgk {
 
@@ -103,30 +105,37 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
             u0[q] = load(phi, ia - 1, q);
             up1[q] = load(phi, ia, q);
             b0[q] = load(b, ia - 1, q);
+            // the step for plane ia - 1 + d takes its requests from buffer (d + 1) % D: see the plane loop
 #pragma unroll
             for (int d = 0; d + 1 < D; d++) {
-                uf[d][q] = load(phi, ia + 1 + d, q);
-                bf[d][q] = load(b, ia + d, q);
+                uf[(d + 1) % D][q] = load(phi, ia + 1 + d, q);
+                bf[(d + 1) % D][q] = load(b, ia + d, q);
             }
         }
         hN0 = load(phi, ia - 1, -1);
         hS0 = load(phi, ia - 1, Q);
 #pragma unroll
         for (int d = 0; d + 1 < D; d++) {
-            hNf[d] = load(phi, ia + d, -1);
-            hSf[d] = load(phi, ia + d, Q);
+            hNf[(d + 1) % D] = load(phi, ia + d, -1);
+            hSf[(d + 1) % D] = load(phi, ia + d, Q);
         }
 
-        for (int p = ia - 1; p < ib; p++) {
+        // One plane step.  The planes requested ahead land in D buffers used in turn, and the loop
+        // is unrolled D times so that each step names its buffers statically (K takes this step's
+        // requests, (K + 1) % D holds what this step hands on): a register with a load in flight is
+        // not touched before the step that needs it, where a chain of register copies would make
+        // every copy wait for its load in the step that issued it.
+        auto step = [&](int p, auto kc) {
+            constexpr int K = decltype(kc)::value, KU = (K + 1) % D;
             const int pl = min(p + 1 + D, ib);
             const int pb = min(p + D, ib);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                uf[D - 1][q] = load(phi, pl, q);
-                bf[D - 1][q] = load(b, pb, q);
+                uf[K][q] = load(phi, pl, q);
+                bf[K][q] = load(b, pb, q);
             }
-            hNf[D - 1] = load(phi, pb, -1);
-            hSf[D - 1] = load(phi, pb, Q);
+            hNf[K] = load(phi, pb, -1);
+            hSf[K] = load(phi, pb, Q);
 
             if (p >= 0) {
                 double(*S)[WK] = ring[p % 3];
@@ -233,20 +242,19 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
             for (int q = 0; q < Q; q++) {
                 um1[q] = u0[q];
                 u0[q] = up1[q];
-                up1[q] = uf[0][q];
-#pragma unroll
-                for (int d = 0; d + 1 < D; d++) uf[d][q] = uf[d + 1][q];
-                b0[q] = bf[0][q];
-#pragma unroll
-                for (int d = 0; d + 1 < D; d++) bf[d][q] = bf[d + 1][q];
+                up1[q] = uf[KU][q];
+                b0[q] = bf[KU][q];
             }
-            hN0 = hNf[0];
-            hS0 = hSf[0];
-#pragma unroll
-            for (int d = 0; d + 1 < D; d++) {
-                hNf[d] = hNf[d + 1];
-                hSf[d] = hSf[d + 1];
-            }
+            hN0 = hNf[KU];
+            hS0 = hSf[KU];
+        };
+        static_assert(D >= 1 && D <= 3, "the plane loop is unrolled for up to three buffers");
+        for (int p = ia - 1; p < ib; p += D) {
+            step(p, std::integral_constant<int, 0>{});
+            if constexpr (D > 1)
+                if (p + 1 < ib) step(p + 1, std::integral_constant<int, 1 % D>{});
+            if constexpr (D > 2)
+                if (p + 2 < ib) step(p + 2, std::integral_constant<int, 2 % D>{});
         }
     }
     // workgroup partial sum, fixed order
@@ -304,7 +312,8 @@ void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const 
 #define LAUNCHW(WJ, D, RF, NT)                                                                        \
     hipLaunchKernelGGL((k_residual_restrict<WJ, 32, D, RF, NT>), dim3(g.order.grid()), dim3(NT), 0, s, phi, b, \
                        Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi, g.order)
-    // Measured and not built any more: prefetch depths 1 and 3, and 512 threads on the 32-row window.
+    // Measured and not built any more: prefetch depths 1 and 3, 512 threads on the 32-row window, and
+    // 1024 threads (two rows per lane) on the 64-row window (+10 %).
     if (window_rows(n) == 64) {
         if (Rf.p) LAUNCHW(64, 2, true, 512);
         else LAUNCHW(64, 2, false, 512);
