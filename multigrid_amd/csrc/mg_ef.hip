@@ -54,14 +54,17 @@ __device__ __forceinline__ double lane_right(double v)
 
 // One axis: m2..p2 are the values at offsets -2..+2 along the axis (only the ones the case needs
 // are meaningful), pos / last the node's index and the last index on the axis.
+__device__ __forceinline__ double ef_num(double m2, double m1, double c0, double p1, double p2,
+                                         int64_t pos, int64_t last)
+{
+    if (pos == 0) return -(-3 * c0 + 4 * p1 - p2);
+    if (pos == last) return -(m2 - 4 * m1 + 3 * c0);
+    return -(p1 - m1);
+}
 __device__ __forceinline__ double ef_axis(double m2, double m1, double c0, double p1, double p2,
                                           int64_t pos, int64_t last, const Coef &two_h)
 {
-    double num;
-    if (pos == 0) num = -(-3 * c0 + 4 * p1 - p2);
-    else if (pos == last) num = -(m2 - 4 * m1 + 3 * c0);
-    else num = -(p1 - m1);
-    return div_d(num, two_h);
+    return div_d(ef_num(m2, m1, c0, p1, p2, pos, last), two_h);
 }
 
 // JR: adjacent rows per lane (window = 4 waves x JR rows).  Columns [0, kmain) are produced.
@@ -141,15 +144,21 @@ __global__ __launch_bounds__(256) void k_compute_ef(View phi, double *__restrict
             if (i == 0) vi2 = unext[q];  // plane 2
             else if (i == ni - 1) vi2 = pair_at(ni - 3, jr[q], kx);
             if (j == 0 || j == nj - 1) vj2 = pair_at(i, j == 0 ? 2 : nj - 3, kx);
-            d2 ex, ey, ez;
-            ex.x = ef_axis(vi2.x, um1[q].x, u.x, up1[q].x, vi2.x, i, ni - 1, hx);
-            ex.y = ef_axis(vi2.y, um1[q].y, u.y, up1[q].y, vi2.y, i, ni - 1, hx);
-            ey.x = ef_axis(vj2.x, vjm.x, u.x, vjp.x, vj2.x, jr[q], nj - 1, hy);
-            ey.y = ef_axis(vj2.y, vjm.y, u.y, vjp.y, vj2.y, jr[q], nj - 1, hy);
+            // numerators of the two nodes per axis, then the quotients of each axis as one batch
+            // (straight-line code behind a single rarely taken branch)
+            double nx[2], ny[2], nz[2], qx[2], qy[2], qz[2];
+            nx[0] = ef_num(vi2.x, um1[q].x, u.x, up1[q].x, vi2.x, i, ni - 1);
+            nx[1] = ef_num(vi2.y, um1[q].y, u.y, up1[q].y, vi2.y, i, ni - 1);
+            ny[0] = ef_num(vj2.x, vjm.x, u.x, vjp.x, vj2.x, jr[q], nj - 1);
+            ny[1] = ef_num(vj2.y, vjm.y, u.y, vjp.y, vj2.y, jr[q], nj - 1);
             // k axis: the first column's second neighbour is column 2 (r1), the last column's are
             // the two columns before it
-            ez.x = ef_axis(l2, l1, u.x, u.y, r1, x_first ? 0 : (x_last ? nk - 1 : 1), nk - 1, hz);
-            ez.y = ef_axis(l1, u.x, u.y, r1, 0.0, y_last ? nk - 1 : 1, nk - 1, hz);
+            nz[0] = ef_num(l2, l1, u.x, u.y, r1, x_first ? 0 : (x_last ? nk - 1 : 1), nk - 1);
+            nz[1] = ef_num(l1, u.x, u.y, r1, 0.0, y_last ? nk - 1 : 1, nk - 1);
+            div_d_n<2>(nx, hx, qx);
+            div_d_n<2>(ny, hy, qy);
+            div_d_n<2>(nz, hz, qz);
+            const d2 ex{qx[0], qx[1]}, ey{qy[0], qy[1]}, ez{qz[0], qz[1]};
             d2 *t2 = reinterpret_cast<d2 *>(t + q * (EF_COLS * 3) + 6 * lane);
             t2[0] = d2{ex.x, ey.x};
             t2[1] = d2{ez.x, ex.y};

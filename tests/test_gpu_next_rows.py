@@ -70,7 +70,10 @@ def test_compute_ef_on_the_handle_follows_the_solve(gpu, orc):
 
 
 @pytest.mark.parametrize("n,max_it", [((17, 17, 17), 60), ((41, 41, 41), 130), ((33, 21, 45), 77),
-                                      ((129, 129, 129), 30), ((140, 150, 160), 27)], ids=str)
+                                      ((129, 129, 129), 30), ((140, 150, 160), 27),
+                                      # batches of sweeps between two norm tests: 1 | 1 + 1 | 1 + 25 | 1 + 25 + 25
+                                      ((129, 129, 129), 1), ((129, 129, 129), 2), ((130, 131, 135), 26),
+                                      ((129, 140, 131), 51)], ids=str)
 def test_gs_sweeps_match_rb_oracle_bit_for_bit(gpu, orc, n, max_it):
     dh, rho = orc.main_extents_dh(n), orc.synthetic_rho(n)
     want = np.zeros(n)
