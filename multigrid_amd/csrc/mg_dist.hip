@@ -247,7 +247,45 @@ struct RcclTransport : Transport {
         HIP_TRY(hipEventCreateWithFlags(&to_cs, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&from_cs, hipEventDisableTiming));
         NCCL_TRY(api->CommInitRank(&comm, world, id, rank));
+        // A world of one never exchanges anything; what it can do is prove that the library was
+        // bound correctly and that its calls run on the communication stream the way start(),
+        // allreduce() and gather() issue them.
+        if (world == 1) TRY(loopback_check());
         return MG_OK;
+    }
+    // Grouped send + receive of a block to this rank itself, then an all-reduce of one value, on the
+    // communication stream ordered after and before a compute stream with the two events.
+    int loopback_check()
+    {
+        constexpr int kCount = 1024;
+        std::vector<double> host(2 * kCount, -1.0);
+        for (int k = 0; k < kCount; k++) host[k] = 1.0 + 0.5 * k;
+        double *buf = nullptr;
+        HIP_TRY(hipMalloc((void **)&buf, 2 * kCount * sizeof(double)));
+        hipStream_t compute = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&compute, hipStreamNonBlocking);
+        int rc = MG_OK;
+        auto body = [&]() -> int {
+            HIP_TRY(e);
+            HIP_TRY(hipMemcpyAsync(buf, host.data(), 2 * kCount * sizeof(double), hipMemcpyHostToDevice, compute));
+            TRY(order_after_compute(compute));
+            NCCL_TRY(api->GroupStart());
+            NCCL_TRY(api->Send(buf, kCount, ncclDouble, rank, comm, cs));
+            NCCL_TRY(api->Recv(buf + kCount, kCount, ncclDouble, rank, comm, cs));
+            NCCL_TRY(api->GroupEnd());
+            NCCL_TRY(api->AllReduce(buf, buf, 1, ncclDouble, ncclSum, comm, cs));
+            TRY(compute_waits(compute));
+            HIP_TRY(hipMemcpyAsync(host.data(), buf, 2 * kCount * sizeof(double), hipMemcpyDeviceToHost, compute));
+            HIP_TRY(hipStreamSynchronize(compute));
+            for (int k = 0; k < kCount; k++)
+                if (host[kCount + k] != 1.0 + 0.5 * k || host[k] != 1.0 + 0.5 * k)
+                    FAIL(MG_ERR_COMM, "RCCL loopback check: element %d came back as %g / %g", k, host[k], host[kCount + k]);
+            return MG_OK;
+        };
+        rc = body();
+        if (compute) hipStreamDestroy(compute);
+        hipFree(buf);
+        return rc;
     }
     int order_after_compute(hipStream_t compute)
     {
@@ -885,7 +923,7 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
     CREATE_TRY(hip_ok(hipEventCreate(&d->ev_b), "hipEventCreate"));
     // the communicator first: its creation is the one step that waits for the other ranks, and a
     // rank that failed later (out of memory, say) must not leave them waiting here
-    if (cfg->transport == MG_TRANSPORT_RCCL && cfg->world > 1) {
+    if (cfg->transport == MG_TRANSPORT_RCCL) {  // a world of one still creates its communicator (and checks it)
         RcclTransport *t = new (std::nothrow) RcclTransport();
         if (!t) {
             mg_dist_destroy(d);

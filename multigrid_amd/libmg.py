@@ -460,7 +460,7 @@ class DistRank:
         if omega is not None:
             dc.base.omega = omega
         dc.rank, dc.world, dc.coarse_cut, dc.no_overlap = rank, world, coarse_cut, int(not overlap)
-        if local_group is not None or world == 1:
+        if local_group is not None or (world == 1 and unique_id is None):
             dc.transport = MG_TRANSPORT_LOCAL
             dc.local_group = local_group._g if local_group is not None else None
         else:

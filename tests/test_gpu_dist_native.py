@@ -128,3 +128,26 @@ def test_rank_failure_does_not_hang_the_group(gpu):
     with pytest.raises(gpu.MgError) as e:
         gpu.Handle(N, problem.main_extents_dh(N), 3, devices=[0] * 16, coarse_cut=3)  # 4 planes per rank < 2^3
     assert "rank" in str(e.value) and "planes" in str(e.value)
+
+
+def test_rccl_transport_in_a_world_of_one(gpu, orc):
+    """The RCCL transport on the one GPU of the test box: a communicator of one rank, whose creation
+    sends a block to itself, receives it and all-reduces a value on the communication stream (the
+    calls the halo exchange, the norm and the gather make), then a solve through that transport."""
+    from multigrid_amd import problem
+    n, depth = 65, 3
+    N = (n, n, n)
+    dh = problem.main_extents_dh(N)
+    d = gpu.DistRank(N, dh, depth, 0, 1, device=0, unique_id=gpu.dist_unique_id(), coarse_cut=2)
+    try:
+        d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
+        d.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
+        ok, cycles, l2 = d.solve(500, 1e-6)
+        lo, phi = d.get_phi_owned()
+    finally:
+        d.close()
+    want = np.zeros(N)
+    w_ok, w_cyc, w_l2, _ = orc.Solver(N, dh, depth).solve(want, orc.synthetic_rho(N), 500, 1e-6, rb=True)
+    assert (ok, cycles) == (w_ok, w_cyc) and lo == 0
+    assert l2 == pytest.approx(w_l2, rel=1e-12)
+    assert_bit_equal(phi, want, "phi through the RCCL transport")
