@@ -130,16 +130,20 @@ __global__ __launch_bounds__(1024) void k_smooth_lds(View u, View rhs, int nI, i
     for (int s = 0; s < sweeps; s++) {
 #pragma unroll
         for (int colour = 0; colour < 2; colour++) {
+            double x[P], g[P];
 #pragma unroll
             for (int q = 0; q < P; q++) {
                 // a thread without a point reads around some interior entry and discards the result
                 const int o = off[colour][q] < 0 ? (1 - colour) * HALF + si + sj + 1 : off[colour][q];
                 const double *p = su + o;
                 const double *pk = p + kodd[colour][q];
-                const double g = div_d(b[colour][q] + c.cx * (p[-si] + p[si]) + c.cy * (p[-sj] + p[sj]) +
-                                       c.cz * (pk[-1] + pk[0]), c);
+                x[q] = b[colour][q] + c.cx * (p[-si] + p[si]) + c.cy * (p[-sj] + p[sj]) + c.cz * (pk[-1] + pk[0]);
+            }
+            div_d_n<P>(x, c, g);  // the quotients of a thread's points behind one branch
+#pragma unroll
+            for (int q = 0; q < P; q++) {
                 const double u0 = cur[colour][q];
-                cur[colour][q] = u0 + omega * (g - u0);
+                cur[colour][q] = u0 + omega * (g[q] - u0);
             }
 #pragma unroll
             for (int q = 0; q < P; q++)  // own entry: same (i, j, k>>1), this colour's half
