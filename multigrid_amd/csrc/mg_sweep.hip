@@ -57,41 +57,52 @@ enum : int {
 template <int E> __device__ __forceinline__ double &elem(d2 &v) { return E ? v.y : v.x; }
 template <int E> __device__ __forceinline__ double elem(const d2 &v) { return E ? v.y : v.x; }
 
-template <int E, int Q, int ROWSTEP, int WK>
-__device__ __forceinline__ void red_phase_impl(double *P, d2 (&v0)[Q], const d2 (&vm1)[Q], const d2 (&vp1)[Q],
-                                               const d2 (&b0)[Q], unsigned okmask, const Coef &c, double omega)
+// Value of lane - 1 / lane + 1 of the wave (lanes 0 / 63, which have no such neighbour, get 0).
+__device__ __forceinline__ double lane_left(double v)
 {
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-        double *X = P + q * ROWSTEP + E;
-        const double uc = elem<E>(v0[q]);
-        const double g = div_d(elem<E>(b0[q]) + c.cx * (elem<E>(vm1[q]) + elem<E>(vp1[q])) +
-                               c.cy * (X[-WK] + X[WK]) + c.cz * (X[-1] + X[1]), c);
-        const bool ok = (okmask >> (E * Q + q)) & 1u;
-        const double un = ok ? uc + omega * (g - uc) : uc;
-        elem<E>(v0[q]) = un;
-        X[0] = un;
-    }
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_right(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
 
-// okmask: bit E * Q + q = the point may be updated in this phase (the caller shifts its phase's
-// bits down).  PUBLISH: the new values also go to the plane's LDS slot, for a later phase of the
-// same march that reads this plane's finished values.
-template <int E, int Q, int ROWSTEP, int WK, bool PUBLISH = false>
-__device__ __forceinline__ void black_phase_impl(double *P, d2 (&vm1)[Q], const d2 (&vm2)[Q],
-                                                 const d2 (&v0)[Q], const d2 (&bm1)[Q], unsigned okmask,
-                                                 const Coef &c, double omega)
+// One colour phase on a plane whose LDS slot keeps the two pair elements apart: element e of
+// (row r, pair m) at e * HALF + (r + 1) * WKP + m.  The j-1 / j+1 neighbours of a point are the
+// same element one row up / down (consecutive lanes read consecutive words: no bank conflicts);
+// of the k-1 / k+1 neighbours one is the lane's other pair element and one the adjacent lane's,
+// fetched by a wave shift (at the ends of a 32-lane row it comes from another row: window-edge
+// columns, never used).  P points at element 0 of (row rw - 1, pair m), the row above the
+// lane's first one, so every access is P plus a non-negative constant; vc is the plane being
+// updated, va / vb its i-1 / i+1 neighbours, all as the lane's registers hold them.
+// okmask: bit E * Q + q = the point may be updated.  PUBLISH: new values also go to the slot.
+template <int E, int Q, int ROWSTEP, int WKP, int HALF, bool PUBLISH>
+__device__ __forceinline__ void phase_split(double *P, d2 (&vc)[Q], const d2 (&va)[Q], const d2 (&vb)[Q],
+                                            const d2 (&b)[Q], unsigned okmask, const Coef &c, double omega)
 {
+    double x[Q], g[Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        double *Y = P + q * ROWSTEP + E;
-        const double uc = elem<E>(vm1[q]);
-        const double g = div_d(elem<E>(bm1[q]) + c.cx * (elem<E>(vm2[q]) + elem<E>(v0[q])) +
-                               c.cy * (Y[-WK] + Y[WK]) + c.cz * (Y[-1] + Y[1]), c);
+        const double *X = P + E * HALF + q * ROWSTEP;
+        const double mate = elem<1 - E>(vc[q]);
+        const double far = E ? lane_right(mate) : lane_left(mate);
+        x[q] = elem<E>(b[q]) + c.cx * (elem<E>(va[q]) + elem<E>(vb[q])) + c.cy * (X[0] + X[2 * WKP]) +
+               c.cz * (E ? mate + far : far + mate);
+    }
+    div_d_n<Q>(x, c, g);
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const double uc = elem<E>(vc[q]);
         const bool ok = (okmask >> (E * Q + q)) & 1u;
-        const double un = ok ? uc + omega * (g - uc) : uc;
-        elem<E>(vm1[q]) = un;
-        if (PUBLISH) Y[0] = un;
+        const double un = ok ? uc + omega * (g[q] - uc) : uc;
+        elem<E>(vc[q]) = un;
+        if (PUBLISH) P[E * HALF + q * ROWSTEP + WKP] = un;
     }
 }
 
@@ -115,7 +126,10 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
     // Three plane slots, each with a guard row above and below the window: the in-plane
     // neighbours of any window point are then plain constant offsets from the point (the values
     // read across a window edge are garbage that only reaches points which are not updated).
-    constexpr int PL = (WJ + 2) * WK;  // doubles per slot
+    static_assert(WKP == 32, "the wave shifts assume 32 lanes per row");
+    constexpr int HALF = (WJ + 2) * WKP;  // one pair element of a plane (see phase_split)
+    constexpr int PL = 2 * HALF;          // doubles per slot
+    constexpr int RS = RPP * WKP;         // from owned row q to q + 1
     __shared__ double lds[3 * PL];
     __shared__ double cl[2][CJ][CKP];  // staged coarse planes; unused (and not allocated) in plain mode
 
@@ -125,8 +139,8 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
     // RPP/2 apart instead of adjacent ones: rows of equal parity have their red point in the same
     // pair element and the same prolongation case, so the wave does not diverge.
     const int rw = (rr >> 1) + (RPP / 2) * (rr & 1);
-    // offset of (row rw, pair m) inside a slot; row q*RPP + rw is q*RPP*WK further
-    const int tbase = (rw + 1) * WK + 2 * m;
+    // element 0 of (row rw - 1, pair m) inside a slot: what phase_split addresses from
+    const int tbase = rw * WKP + m;
     // plain order: chunk index fastest (with a multiple of 8 chunks all windows of a chunk share
     // blockIdx % 8, i.e. one XCD); blocked order: chunk slowest, each XCD a contiguous run of windows
     const int item = order.item(blockIdx.x);
@@ -288,10 +302,23 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
         }
         // staged now: planes ia>>1 and (ia>>1)+1, which is also what plane ia+1 needs
     }
+    // slot of plane p - back, given sp = slot of plane p (a small loop-carried index, so that the
+    // slot offset folds into the LDS instructions' immediate offsets)
+    int sp = (ia - 1 + 3) % 3;
+    auto slot = [&](int back) -> double * {
+        int t = sp - back;
+        t = t < 0 ? t + 3 : (t >= 3 ? t - 3 : t);
+        return lds + (unsigned)(t * PL + tbase);
+    };
+    auto fill = [&](int back, const d2 (&v)[Q]) {
+        double *S = slot(back);
 #pragma unroll
-    for (int q = 0; q < Q; q++) {
-        *reinterpret_cast<d2 *>(&lds[((ia - 1 + 3) % 3) * PL + tbase + q * RPP * WK]) = v0[q];
-    }
+        for (int q = 0; q < Q; q++) {
+            S[WKP + q * RS] = v[q].x;
+            S[WKP + HALF + q * RS] = v[q].y;
+        }
+    };
+    fill(0, v0);
 
     // Which of this lane's points may be updated, per phase (red: window minus one ring, black:
     // minus two), pair element E and row q: bit (phase*2 + E)*Q + q.  Loop invariant.
@@ -331,9 +358,8 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
         // of a wave take rows of equal parity: which element of a pair is red is wave-uniform.
         const bool e1 = __builtin_amdgcn_readfirstlane((p + j0 + rw) & 1) != 0;
         if (p >= 1 && p <= nI - 2) {
-            double *X = &lds[((p + 3) % 3) * PL + tbase];
-            if (e1) red_phase_impl<1, Q, RPP * WK, WK>(X, v0, vm1, vp1, b0, okmask, c, omega);
-            else red_phase_impl<0, Q, RPP * WK, WK>(X, v0, vm1, vp1, b0, okmask, c, omega);
+            if (e1) phase_split<1, Q, RS, WKP, HALF, true>(slot(0), v0, vm1, vp1, b0, okmask, c, omega);
+            else phase_split<0, Q, RS, WKP, HALF, true>(slot(0), v0, vm1, vp1, b0, okmask, c, omega);
         }
         if (MODE != kLoadPlain && !(f & 1)) stage_write((f >> 1) + 1, cv);
         // No barrier between the phases: the black update of plane p-1 reads, from other lanes,
@@ -346,9 +372,8 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
         if (pb >= ia && pb < ib) {
             if (pb >= 1 && pb <= nI - 2) {
                 // black of plane p-1 sits where red of plane p does
-                double *Y = &lds[((pb + 3) % 3) * PL + tbase];
-                if (e1) black_phase_impl<1, Q, RPP * WK, WK>(Y, vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
-                else black_phase_impl<0, Q, RPP * WK, WK>(Y, vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
+                if (e1) phase_split<1, Q, RS, WKP, HALF, false>(slot(1), vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
+                else phase_split<0, Q, RS, WKP, HALF, false>(slot(1), vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) {
@@ -359,9 +384,10 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
             }
         }
         // plane p+1 into the LDS slot plane p-2 occupied; plane p+2 arrives and is fixed
+        fill(-1, vp1);
+        sp = sp == 2 ? 0 : sp + 1;
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            *reinterpret_cast<d2 *>(&lds[((p + 1 + 3) % 3) * PL + tbase + q * RPP * WK]) = vp1[q];
             vm2[q] = vm1[q];
             vm1[q] = v0[q];
             v0[q] = vp1[q];
@@ -374,55 +400,6 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
                 bf[d][q] = bf[d + 1][q];
             }
         }
-    }
-}
-
-// Value of lane - 1 / lane + 1 of the wave (lanes 0 / 63, which have no such neighbour, get 0).
-__device__ __forceinline__ double lane_left(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lane_right(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-// One colour phase on a plane whose LDS slot keeps the two pair elements apart: element e of
-// (row r, pair m) at e * HALF + (r + 1) * WKP + m.  The j-1 / j+1 neighbours of a point are the
-// same element one row up / down (consecutive lanes read consecutive words: no bank conflicts);
-// of the k-1 / k+1 neighbours one is the lane's other pair element and one the adjacent lane's,
-// fetched by a wave shift (at the ends of a 32-lane row it comes from another row: window-edge
-// columns, never used).  P points at element 0 of (row rw - 1, pair m), the row above the
-// lane's first one, so every access is P plus a non-negative constant; vc is the plane being
-// updated, va / vb its i-1 / i+1 neighbours, all as the lane's registers hold them.
-// okmask: bit E * Q + q = the point may be updated.  PUBLISH: new values also go to the slot.
-template <int E, int Q, int ROWSTEP, int WKP, int HALF, bool PUBLISH>
-__device__ __forceinline__ void phase_split(double *P, d2 (&vc)[Q], const d2 (&va)[Q], const d2 (&vb)[Q],
-                                            const d2 (&b)[Q], unsigned okmask, const Coef &c, double omega)
-{
-    double x[Q], g[Q];
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-        const double *X = P + E * HALF + q * ROWSTEP;
-        const double mate = elem<1 - E>(vc[q]);
-        const double far = E ? lane_right(mate) : lane_left(mate);
-        x[q] = elem<E>(b[q]) + c.cx * (elem<E>(va[q]) + elem<E>(vb[q])) + c.cy * (X[0] + X[2 * WKP]) +
-               c.cz * (E ? mate + far : far + mate);
-    }
-    div_d_n<Q>(x, c, g);
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-        const double uc = elem<E>(vc[q]);
-        const bool ok = (okmask >> (E * Q + q)) & 1u;
-        const double un = ok ? uc + omega * (g[q] - uc) : uc;
-        elem<E>(vc[q]) = un;
-        if (PUBLISH) P[E * HALF + q * ROWSTEP + WKP] = un;
     }
 }
 
