@@ -86,7 +86,6 @@ void MultiGridSolverHIP::init(int depth, int device, bool variant_b, const std::
     else check(mg_default_config(&cfg, world.ni, world.nj, world.nk, h, depth), "mg_default_config");
     cfg.device = device;
     if (devices.size() > 1) {
-        multi_gpu = true;
         cfg.n_gpus = int(devices.size());
         for (std::size_t g = 0; g < devices.size(); g++) cfg.devices[g] = devices[g];
         cfg.coarse_cut = coarse_cut;
@@ -196,10 +195,6 @@ int GaussSeidelSolverHIP::iterate(int *converged)
 // there when world.phi still is that potential, after an upload otherwise.
 void MultiGridSolverHIP::computeEF()
 {
-    if (multi_gpu) {  // the slabs hold phi; the field is differentiated on the host copy
-        PotentialSolver::computeEF();
-        return;
-    }
     try {
         upload_phi_if_stale();
         check(mg_compute_ef(handle), "mg_compute_ef");

@@ -52,7 +52,7 @@ public:
     // The grid split into slabs of i-planes over several GPUs (one host thread per GPU inside the
     // library, halo planes over RCCL; an ordinal may repeat, e.g. {0, 0}: two slabs on one GPU).
     // coarse_cut: first level solved whole on devices[0] (0 = the first with <= 128 planes).
-    // computeEF() of such a solver is the host loop on the downloaded potential.
+    // computeEF() differentiates each slab on its own GPU.
     MultiGridSolverHIP(World &world, int max_it, double tol, int depth, const std::vector<int> &devices,
                        int coarse_cut = 0);
     ~MultiGridSolverHIP() override;
@@ -86,7 +86,6 @@ protected:
 private:
     void init(int depth, int device, bool variant_b, const std::vector<int> &devices, int coarse_cut);
     const double *pack(Field &f);
-    bool multi_gpu = false;
     bool device_phi_current();
     void remember_phi();
     void upload_phi_if_stale();

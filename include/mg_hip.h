@@ -397,6 +397,11 @@ int mg_dist_get_phi_planes(mg_dist *d, int64_t lo, int64_t hi, double *dense);
 /* As mg_vcycles / mg_solve; every rank receives the same norm and the same stopping decision. */
 int mg_dist_vcycles(mg_dist *d, unsigned count, double *L2);
 int mg_dist_solve(mg_dist *d, unsigned max_it, double tol, int *converged, unsigned *cycles, double *L2);
+/* E = -grad(phi) on the rank's owned planes (collective: phi's halo planes are exchanged first), as
+ * PotentialSolver::computeEF (cpp/PotentialSolver.cpp:418-458); then planes [lo,hi) within the
+ * owned range as dense [plane][nj][nk][3]. */
+int mg_dist_compute_ef(mg_dist *d);
+int mg_dist_get_ef_planes(mg_dist *d, int64_t lo, int64_t hi, double *dense);
 int mg_dist_sync(mg_dist *d);
 /* Device time of the last vcycles/solve call and bytes this rank has sent so far. */
 int mg_dist_stats(mg_dist *d, double *last_ms, uint64_t *bytes_sent);

@@ -621,6 +621,7 @@ int mg_set_phi(mg_handle *h, const double *phi_flat)
     if (h->multi) {
         int rc = multi_upload(h, phi_flat, false);
         if (!rc) h->have_phi = true;
+        h->have_ef = false;
         return rc;
     }
     HIP_TRY(hipSetDevice(h->cfg.device));
@@ -652,6 +653,7 @@ int mg_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsigned
 {
     if (h && h->multi) {
         if (!h->have_rho || !h->have_phi) return fail(MG_ERR_STATE, "mg_set_rho and mg_set_phi must be called before solving");
+        h->have_ef = false;
         const int n = (int)h->multi->ranks.size();
         std::vector<int> conv(n, 0);
         std::vector<unsigned> cyc(n, 0);
@@ -702,6 +704,7 @@ int mg_vcycles(mg_handle *h, unsigned count, double *L2)
 {
     if (h && h->multi) {
         if (!h->have_rho || !h->have_phi) return fail(MG_ERR_STATE, "mg_set_rho and mg_set_phi must be called before solving");
+        h->have_ef = false;
         std::vector<double> l2(h->multi->ranks.size(), 0.0);
         int rc = on_all_ranks(h->multi, [&](int r) { return mg_dist_vcycles(h->multi->ranks[r], count, &l2[r]); });
         if (rc) return rc;
@@ -790,7 +793,12 @@ int mg_gs_solve(mg_handle *h, unsigned max_it, double tol, int *converged, unsig
 int mg_compute_ef(mg_handle *h)
 {
     if (!h) return fail(MG_ERR_INVALID, "null handle");
-    TRY(single_gpu_only(h, "mg_compute_ef"));
+    if (h->multi) {
+        if (!h->have_phi) return fail(MG_ERR_STATE, "no phi on the device yet");
+        int rc = on_all_ranks(h->multi, [&](int r) { return mg_dist_compute_ef(h->multi->ranks[r]); });
+        if (!rc) h->have_ef = true;
+        return rc;
+    }
     if (!h->have_phi) return fail(MG_ERR_STATE, "no phi on the device yet");
     HIP_TRY(hipSetDevice(h->cfg.device));
     const int64_t *n = h->lv[0].n;
@@ -814,8 +822,16 @@ int mg_compute_ef(mg_handle *h)
 int mg_get_ef(mg_handle *h, double *ef_flat)
 {
     if (!h || !ef_flat) return fail(MG_ERR_INVALID, "null argument");
-    TRY(single_gpu_only(h, "mg_get_ef"));
     if (!h->have_ef) return fail(MG_ERR_STATE, "mg_compute_ef has not run on the current phi");
+    if (h->multi) {
+        const size_t plane = (size_t)h->cfg.n[1] * (size_t)h->cfg.n[2] * 3;
+        return on_all_ranks(h->multi, [&](int r) {
+            int64_t own[2];
+            int rc = mg_dist_plan(h->multi->ranks[r], nullptr, own, nullptr, nullptr);
+            if (rc) return rc;
+            return mg_dist_get_ef_planes(h->multi->ranks[r], own[0], own[1], ef_flat + (size_t)own[0] * plane);
+        });
+    }
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipMemcpyAsync(ef_flat, h->ef, (size_t)count3(h->lv[0].n) * 3 * sizeof(double), hipMemcpyDeviceToHost,
                            h->stream));

@@ -540,6 +540,9 @@ struct mg_dist {
     double *d_sum = nullptr;  // this rank's, then the global, sum of squared residuals
     double *h_sum = nullptr;  // pinned
     double n_nodes = 0;
+    double dh[3] = {0, 0, 0};
+    double *ef = nullptr;  // E on the owned planes, dense [plane][nj][nk][3]; allocated by the first mg_dist_compute_ef
+    bool have_ef = false;
     bool correction_pending = false, have_rho = false, have_phi = false;
     double last_ms = 0;
 
@@ -912,6 +915,7 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
     CREATE_TRY(d->plan.init(base.n, base.depth, cfg->world, cfg->coarse_cut));
     d->cut = d->plan.cut;
     d->n_nodes = (double)base.n[0] * (double)base.n[1] * (double)base.n[2];
+    for (int a = 0; a < 3; a++) d->dh[a] = base.dh[a];
     for (int l = 0; l <= d->L; l++) {
         d->nu[l] = base.nu[l];
         double k[4];
@@ -1005,6 +1009,7 @@ int mg_dist_set_phi_planes(mg_dist *d, int64_t lo, int64_t hi, const double *den
     if (d->phi.pending) FAIL(MG_ERR_STATE, "a halo exchange of phi is still in flight");
     TRY(upload_planes(d, d->phi, lo, hi, dense, false));
     d->have_phi = true;
+    d->have_ef = false;
     d->correction_pending = false;
     return MG_OK;
 }
@@ -1042,6 +1047,7 @@ int mg_dist_get_phi_planes(mg_dist *d, int64_t lo, int64_t hi, double *dense)
 int mg_dist_vcycles(mg_dist *d, unsigned count, double *L2)
 {
     TRY(check_rank(d, true));
+    d->have_ef = false;
     HIP_TRY(hipEventRecord(d->ev_a, d->stream));
     for (unsigned it = 0; it < count; it++) {
         TRY(d->smooth_and_residual());
@@ -1061,6 +1067,7 @@ int mg_dist_vcycles(mg_dist *d, unsigned count, double *L2)
 int mg_dist_solve(mg_dist *d, unsigned max_it, double tol, int *converged, unsigned *cycles, double *L2)
 {
     TRY(check_rank(d, true));
+    d->have_ef = false;
     bool conv = false;
     double l2 = 0;
     unsigned it = 0;
@@ -1086,6 +1093,45 @@ int mg_dist_solve(mg_dist *d, unsigned max_it, double tol, int *converged, unsig
     if (converged) *converged = conv ? 1 : 0;
     if (cycles) *cycles = it;
     if (L2) *L2 = l2;
+    return MG_OK;
+}
+
+int mg_dist_compute_ef(mg_dist *d)
+{
+    TRY(check_rank(d, false));
+    if (!d->have_phi) FAIL(MG_ERR_STATE, "no phi on the device yet");
+    const IRange o = d->own(0, false);
+    const int64_t *n = d->plan.n0;
+    // the central differences read one halo plane per side; the one-sided formulas on the two outer
+    // faces of the grid read planes 0..2 / n-3..n-1, which the outer ranks' stored planes must cover
+    if ((o.lo == 0 && d->phi.v.i_end() < 3) || (o.hi == n[0] && d->phi.v.i0 > n[0] - 3))
+        FAIL(MG_ERR_STATE, "an outer rank stores fewer than three planes: the field on the grid's faces needs three");
+    if (!d->ef) {
+        HIP_TRY(hipMalloc((void **)&d->ef, (size_t)(o.hi - o.lo) * n[1] * n[2] * 3 * sizeof(double)));
+        d->blocks.push_back(d->ef);
+    }
+    TRY(d->flush_correction());
+    // phi's halo planes must be those of the neighbours' current potential
+    TRY(d->tr->start(d->phi, o, H_U, d->stream));
+    TRY(d->tr->finish(d->phi, d->stream));
+    mgk::compute_ef(d->stream, d->phi.v, d->ef, o.lo, n, d->dh, o);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    d->have_ef = true;
+    return MG_OK;
+}
+
+int mg_dist_get_ef_planes(mg_dist *d, int64_t lo, int64_t hi, double *dense)
+{
+    TRY(check_rank(d, false));
+    if (!dense) FAIL(MG_ERR_INVALID, "null argument");
+    if (!d->have_ef) FAIL(MG_ERR_STATE, "mg_dist_compute_ef has not run on the current phi");
+    const IRange o = d->own(0, false);
+    if (lo < o.lo || hi > o.hi || lo >= hi) FAIL(MG_ERR_INVALID, "planes [%lld,%lld) outside the owned range [%lld,%lld)", (long long)lo, (long long)hi, (long long)o.lo, (long long)o.hi);
+    const size_t plane = (size_t)d->plan.n0[1] * d->plan.n0[2] * 3;
+    HIP_TRY(hipMemcpyAsync(dense, d->ef + (size_t)(lo - o.lo) * plane, (size_t)(hi - lo) * plane * sizeof(double),
+                           hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
     return MG_OK;
 }
 

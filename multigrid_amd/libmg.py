@@ -137,6 +137,8 @@ SYMBOLS = {
     "mg_dist_get_phi_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
     "mg_dist_vcycles": (C.c_int, [C.c_void_p, C.c_uint, _dp]),
     "mg_dist_solve": (C.c_int, [C.c_void_p, C.c_uint, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_uint), _dp]),
+    "mg_dist_compute_ef": (C.c_int, [C.c_void_p]),
+    "mg_dist_get_ef_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
     "mg_dist_sync": (C.c_int, [C.c_void_p]),
     "mg_dist_stats": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_uint64)]),
 }
@@ -511,6 +513,14 @@ class DistRank:
         conv, cyc, l2 = C.c_int(0), C.c_uint(0), C.c_double(0)
         _check(load().mg_dist_solve(self._d, max_it, tol, C.byref(conv), C.byref(cyc), C.byref(l2)))
         return bool(conv.value), cyc.value, l2.value
+
+    def compute_ef_owned(self):
+        """(first owned plane, E on the owned planes as (planes, nj, nk, 3)); collective."""
+        _check(load().mg_dist_compute_ef(self._d))
+        lo, hi = self.own
+        out = np.empty((hi - lo,) + self.n[1:] + (3,))
+        _check(load().mg_dist_get_ef_planes(self._d, lo, hi, _out(out)))
+        return lo, out
 
     def sync(self):
         _check(load().mg_dist_sync(self._d))

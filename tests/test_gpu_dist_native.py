@@ -117,8 +117,13 @@ def test_multi_gpu_handle_equals_single_gpu_handle(gpu, orc, devices, n, depth):
         assert a[:2] == b[:2] and b[2] == pytest.approx(a[2], rel=1e-12)
         assert_bit_equal(many.get_phi(), one.get_phi(), "converged")
         assert many.last_call_ms() > 0
-        with pytest.raises(gpu.MgError):
-            many.compute_ef()
+        with pytest.raises(gpu.MgError):  # no field computed on the current potential yet
+            many.get_ef()
+        assert_bit_equal(many.compute_ef(), one.compute_ef(), "E from the slabs")
+        assert_bit_equal(many.compute_ef(), orc.compute_ef(one.get_phi(), dh), "E against the oracle")
+        many.vcycles(1)
+        with pytest.raises(gpu.MgError):  # stale after a cycle
+            many.get_ef()
 
 
 def test_rank_failure_does_not_hang_the_group(gpu):

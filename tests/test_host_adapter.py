@@ -172,8 +172,8 @@ def test_driver_writes_vti_of_the_solution(box, gpu, orc, tmp_path):
 @pytest.mark.gpu
 def test_multi_gpu_solver_behind_the_same_interface(box, gpu, tmp_path):
     """MultiGridSolverHIP(world, max_it, tol, depth, {0, 0, 0}): three slabs (here all on GPU 0) behind
-    PotentialSolver::solve() give the single-GPU solver's potential bit for bit; computeEF() falls
-    back to the host loop on the downloaded potential and agrees too."""
+    PotentialSolver::solve() give the single-GPU solver's potential bit for bit; computeEF()
+    differentiates each slab on its GPU and agrees too."""
     outs = []
     for extra in ([], ["--gpus", "0,0,0"]):
         phi, ef = tmp_path / f"phi{len(extra)}.bin", tmp_path / f"ef{len(extra)}.bin"
@@ -183,4 +183,4 @@ def test_multi_gpu_solver_behind_the_same_interface(box, gpu, tmp_path):
         outs.append((np.fromfile(phi), np.fromfile(ef), [l for l in p.stdout.splitlines() if "converged=" in l][0].split()[:2]))
     assert outs[0][2] == outs[1][2]
     assert_bit_equal(outs[1][0], outs[0][0], "phi from three slabs")
-    assert_bit_equal(outs[1][1], outs[0][1], "E from the host loop")
+    assert_bit_equal(outs[1][1], outs[0][1], "E from the slabs")
