@@ -85,16 +85,16 @@ __host__ __device__ inline size_t smooth_lds_doubles(int64_t uI, int64_t uJ, int
     return (size_t)(2 * uI * uJ * ((uK + 1) / 2));
 }
 
-template <int P>
-__global__ __launch_bounds__(1024) void k_smooth_lds(View u, View rhs, int nI, int nJ, int nK,
-                                                     Coef c, double omega, int sweeps)
+template <int P, int NT = 1024>
+__global__ __launch_bounds__(NT) void k_smooth_lds(View u, View rhs, int nI, int nJ, int nK,
+                                                   Coef c, double omega, int sweeps)
 {
     extern __shared__ __align__(16) double su[];
     const int uI = (int)u.d[0], uJ = (int)u.d[1], uK = (int)u.d[2];
     const int H = (uK + 1) / 2, HALF = uI * uJ * H;
     const int tid = threadIdx.x;
     auto lds_at = [&](int i, int j, int k) { return ((i + j + k) & 1) * HALF + (i * uJ + j) * H + (k >> 1); };
-    for (int p = tid; p < uI * uJ * uK; p += 1024) {
+    for (int p = tid; p < uI * uJ * uK; p += NT) {
         const int k = p % uK, j = (p / uK) % uJ, i = p / (uK * uJ);
         su[lds_at(i, j, k)] = u.p[u.at(i, j, k)];
     }
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(1024) void k_smooth_lds(View u, View rhs, int nI, i
     for (int colour = 0; colour < 2; colour++)
 #pragma unroll
         for (int q = 0; q < P; q++) {
-            const int idx = tid + q * 1024;
+            const int idx = tid + q * NT;
             off[colour][q] = -1;
             kodd[colour][q] = 0;
             b[colour][q] = 0.0;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(1024) void k_smooth_lds(View u, View rhs, int nI, i
             __syncthreads();
         }
     }
-    for (int p = tid; p < uI * uJ * uK; p += 1024) {
+    for (int p = tid; p < uI * uJ * uK; p += NT) {
         const int k = p % uK, j = (p / uK) % uJ, i = p / (uK * uJ);
         u.p[u.at(i, j, k)] = su[lds_at(i, j, k)];
     }
@@ -424,17 +424,24 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
     const size_t lds_bytes = sizeof(double) * smooth_lds_doubles(u->d[0], u->d[1], u->d[2]);
     const int64_t per_colour = (n[0] - 2) * (n[1] - 2) * ((n[2] - 1) / 2);
     static const bool lds_ok = [] {
-        return hipFuncSetAttribute((const void *)k_smooth_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   kLdsSmoothMaxBytes) == hipSuccess &&
-               hipFuncSetAttribute((const void *)k_smooth_lds<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   kLdsSmoothMaxBytes) == hipSuccess;
+        bool ok = true;
+        for (const void *f : {(const void *)k_smooth_lds<2, 256>, (const void *)k_smooth_lds<2, 1024>,
+                              (const void *)k_smooth_lds<4, 1024>})
+            ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsSmoothMaxBytes) == hipSuccess;
+        return ok;
     }();
     if (whole && lds_ok && lds_bytes <= (size_t)kLdsSmoothMaxBytes && per_colour <= 4 * 1024 && sweeps > 0) {
-        if (per_colour <= 2 * 1024)
-            hipLaunchKernelGGL(k_smooth_lds<2>, dim3(1), dim3(1024), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
+        // Thread count by measurement (50 sweeps; 256 / 512 / 1024 threads): 365 points per colour
+        // 31 / 37 / 53 us, 1372 points 98 / 74 / 68 us, 2916 points - / 148 / 125 us.  The phases of a
+        // tiny level are latency (fewer waves meet at the barriers), those of a larger one throughput.
+        if (per_colour <= 2 * 256)
+            hipLaunchKernelGGL((k_smooth_lds<2, 256>), dim3(1), dim3(256), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
+                               (int)n[2], c, omega, sweeps);
+        else if (per_colour <= 2 * 1024)
+            hipLaunchKernelGGL((k_smooth_lds<2, 1024>), dim3(1), dim3(1024), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
                                (int)n[2], c, omega, sweeps);
         else
-            hipLaunchKernelGGL(k_smooth_lds<4>, dim3(1), dim3(1024), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
+            hipLaunchKernelGGL((k_smooth_lds<4, 1024>), dim3(1), dim3(1024), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
                                (int)n[2], c, omega, sweeps);
         return 1;
     }
