@@ -12,13 +12,14 @@
 // Workgroups are numbered XCD-blocked (WgOrder) so that the lines shared with neighbouring windows
 // are fetched once per L2.  The three components of a node are adjacent in the output
 // ([i][j][k][3], the layout of the reference's Field_<double3>): each wave passes a row through
-// its own LDS row image and stores it as contiguous 8-byte words (a row of the output starts on
-// an 8-byte, not a 16-byte boundary).
+// its own LDS row image and stores it as contiguous 16-byte words laid over the output's 128-byte
+// lines (a row of the output starts on an 8-byte boundary: the doubles in front of the first line
+// boundary go out as one short store).
 //
 // Grids of 2^m + 1 nodes leave one column over after the last full window; a window for it would
 // be a workgroup doing 1/128 of a window's work (20 % more workgroups at 513 columns).  The
-// marching kernel therefore covers the columns up to the last multiple of 128 and a plain
-// one-thread-per-node kernel the few columns left.
+// marching windows therefore cover the columns up to the last multiple of 128 and extra
+// workgroups of the same launch, one per plane, the few columns left, node by node.
 #include "mg_kernels.h"
 
 namespace mgk {
@@ -28,6 +29,7 @@ namespace {
 constexpr int EF_COLS = 128;
 
 struct alignas(16) d2 { double x, y; };
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 struct EfGeom {
     int ktiles, jtiles, chunks;
@@ -67,7 +69,39 @@ __device__ __forceinline__ double ef_axis(double m2, double m1, double c0, doubl
     return div_d(ef_num(m2, m1, c0, p1, p2, pos, last), two_h);
 }
 
-// JR: adjacent rows per lane (window = 4 waves x JR rows).  Columns [0, kmain) are produced.
+// The same operator node by node for columns [kbeg, nk) of plane i: the few columns the marching
+// windows leave over.  Every operand is a plain load; the workgroup's threads share the plane's
+// nodes.
+__device__ __forceinline__ void ef_columns_of_plane(const View &phi, double *__restrict__ ef, int64_t ef_i0, int64_t ni,
+                                                    int64_t kbeg, const Coef &hx, const Coef &hy, const Coef &hz,
+                                                    int64_t i)
+{
+    const int64_t nj = phi.d[1], nk = phi.d[2];
+    const int64_t ncol = nk - kbeg;
+    const double *p = phi.p;
+    auto at = [&](int64_t a, int64_t b, int64_t c) { return p[phi.at(a, b, c)]; };
+    for (int64_t t = threadIdx.x; t < nj * ncol; t += blockDim.x) {
+        const int64_t k = kbeg + t % ncol, j = t / ncol;
+        const double c0 = at(i, j, k);
+        // offsets -2..+2 along each axis, clamped where the one-sided case does not read them
+        auto axis = [&](int a, int64_t pos, int64_t last, const Coef &h) {
+            auto v = [&](int64_t s) {
+                const int64_t q = clampi(pos + s, 0, last);
+                return a == 0 ? at(q, j, k) : (a == 1 ? at(i, q, k) : at(i, j, q));
+            };
+            return ef_axis(v(-2), v(-1), c0, v(1), v(2), pos, last, h);
+        };
+        double *out = ef + (((i - ef_i0) * nj + j) * nk + k) * 3;
+        out[0] = axis(0, i, ni - 1, hx);
+        out[1] = axis(1, j, nj - 1, hy);
+        out[2] = axis(2, k, nk - 1, hz);
+    }
+}
+
+// JR: adjacent rows per lane (window = 4 waves x JR rows).  The first windows x chunks workgroups
+// march and produce columns [0, kmain); each workgroup after them takes columns [kmain, nk) of one
+// plane, in the same launch, so that this latency-bound remainder runs beside the windows instead
+// of behind them.
 template <int JR>
 __global__ __launch_bounds__(256) void k_compute_ef(View phi, double *__restrict__ ef, int64_t ef_i0,
                                                     int64_t ni, int64_t kmain, Coef hx, Coef hy, Coef hz, IRange r,
@@ -75,6 +109,12 @@ __global__ __launch_bounds__(256) void k_compute_ef(View phi, double *__restrict
 {
     constexpr int ROWS = 4 * JR;
     __shared__ __align__(16) double tile[4][JR][EF_COLS * 3];  // per wave: one output row image per owned row
+    if (blockIdx.x >= order.grid()) {  // uniform per workgroup
+        // dealt round-robin to the XCDs like any run of workgroup indices, and last: they fill the
+        // slots the final, partly filled round of marching workgroups leaves free
+        ef_columns_of_plane(phi, ef, ef_i0, ni, kmain, hx, hy, hz, r.lo + (blockIdx.x - order.grid()));
+        return;
+    }
     const int item = order.item(blockIdx.x);
     if (item < 0) return;  // grid padding; uniform per workgroup
     const int64_t nj = phi.d[1], nk = phi.d[2];
@@ -120,6 +160,7 @@ __global__ __launch_bounds__(256) void k_compute_ef(View phi, double *__restrict
     const int seg_len = (int)(cols_here * 3);
     double *t = &tile[wave][0][0];
     const bool x_first = kx == 0, x_last = kx == nk - 1, y_last = kx + 1 == nk - 1;
+    const bool k_face = x_first || x_last || y_last;
 
     for (int64_t i = lo; i < hi; i++) {
         d2 unext[JR], edge_next[JR];
@@ -140,21 +181,33 @@ __global__ __launch_bounds__(256) void k_compute_ef(View phi, double *__restrict
             double l2 = lane_left(u.x), l1 = lane_left(u.y), r1 = lane_right(u.x);
             if (lane == 0) { l2 = edge[q].x; l1 = edge[q].y; }
             if (lane == 63) r1 = edge[q].x;
-            d2 vi2{0.0, 0.0}, vj2{0.0, 0.0};
-            if (i == 0) vi2 = unext[q];  // plane 2
-            else if (i == ni - 1) vi2 = pair_at(ni - 3, jr[q], kx);
-            if (j == 0 || j == nj - 1) vj2 = pair_at(i, j == 0 ? 2 : nj - 3, kx);
-            // numerators of the two nodes per axis, then the quotients of each axis as one batch
-            // (straight-line code behind a single rarely taken branch)
+            // Numerators of the two nodes per axis: the central difference everywhere, replaced by
+            // the one-sided form on a face.  A face in i or j is a whole plane or a whole row of
+            // the wave (scalar branches), a face in k is one lane of the waves at either end of a
+            // row: no node inside the grid evaluates a one-sided formula only to discard it.
             double nx[2], ny[2], nz[2], qx[2], qy[2], qz[2];
-            nx[0] = ef_num(vi2.x, um1[q].x, u.x, up1[q].x, vi2.x, i, ni - 1);
-            nx[1] = ef_num(vi2.y, um1[q].y, u.y, up1[q].y, vi2.y, i, ni - 1);
-            ny[0] = ef_num(vj2.x, vjm.x, u.x, vjp.x, vj2.x, jr[q], nj - 1);
-            ny[1] = ef_num(vj2.y, vjm.y, u.y, vjp.y, vj2.y, jr[q], nj - 1);
-            // k axis: the first column's second neighbour is column 2 (r1), the last column's are
-            // the two columns before it
-            nz[0] = ef_num(l2, l1, u.x, u.y, r1, x_first ? 0 : (x_last ? nk - 1 : 1), nk - 1);
-            nz[1] = ef_num(l1, u.x, u.y, r1, 0.0, y_last ? nk - 1 : 1, nk - 1);
+            nx[0] = -(up1[q].x - um1[q].x);
+            nx[1] = -(up1[q].y - um1[q].y);
+            ny[0] = -(vjp.x - vjm.x);
+            ny[1] = -(vjp.y - vjm.y);
+            nz[0] = -(u.y - l1);
+            nz[1] = -(r1 - u.x);
+            if (i == 0 || i == ni - 1) {
+                const d2 vi2 = i == 0 ? unext[q] /* plane 2 */ : pair_at(ni - 3, jr[q], kx);
+                nx[0] = ef_num(vi2.x, um1[q].x, u.x, up1[q].x, vi2.x, i, ni - 1);
+                nx[1] = ef_num(vi2.y, um1[q].y, u.y, up1[q].y, vi2.y, i, ni - 1);
+            }
+            if (j == 0 || j == nj - 1) {
+                const d2 vj2 = pair_at(i, j == 0 ? 2 : nj - 3, kx);
+                ny[0] = ef_num(vj2.x, vjm.x, u.x, vjp.x, vj2.x, j, nj - 1);
+                ny[1] = ef_num(vj2.y, vjm.y, u.y, vjp.y, vj2.y, j, nj - 1);
+            }
+            if (k_face) {
+                // the first column's second neighbour is column 2 (r1), the last column's are the
+                // two columns before it
+                nz[0] = ef_num(l2, l1, u.x, u.y, r1, x_first ? 0 : (x_last ? nk - 1 : 1), nk - 1);
+                nz[1] = ef_num(l1, u.x, u.y, r1, 0.0, y_last ? nk - 1 : 1, nk - 1);
+            }
             div_d_n<2>(nx, hx, qx);
             div_d_n<2>(ny, hy, qy);
             div_d_n<2>(nz, hz, qz);
@@ -173,11 +226,22 @@ __global__ __launch_bounds__(256) void k_compute_ef(View phi, double *__restrict
             if (j < nj) {  // wave-uniform
                 double *out = ef + ((i - ef_i0) * nj + j) * row_doubles + seg0;
                 const double *tq = t + q * (EF_COLS * 3);
+                // Written once and read by nobody on the device: non-temporal stores (measured -10 %),
+                // 16 bytes per lane and laid over the 128-byte lines of the output: the doubles in front
+                // of the segment's first line boundary go out as one short store, everything behind it
+                // as stores that each cover eight whole lines (measured -5 % against 8-byte stores that
+                // start at the segment's first double, whatever its alignment).
+                const int head = (int)(((128 - (reinterpret_cast<uintptr_t>(out) & 127)) & 127) >> 3);
+                if (lane < head && lane < seg_len) __builtin_nontemporal_store(tq[lane], out + lane);
 #pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    const int e = lane + 64 * c;
-                    // written once, read by nobody on the device: non-temporal (measured -10 %)
-                    if (e < seg_len) __builtin_nontemporal_store(tq[e], out + e);
+                for (int c = 0; c < 3; c++) {
+                    const int e = head + 2 * (lane + 64 * c);
+                    if (e + 1 < seg_len) {
+                        const v2d v = {tq[e], tq[e + 1]};
+                        __builtin_nontemporal_store(v, reinterpret_cast<v2d *>(out + e));
+                    } else if (e < seg_len) {
+                        __builtin_nontemporal_store(tq[e], out + e);
+                    }
                 }
             }
         }
@@ -194,42 +258,14 @@ __global__ __launch_bounds__(256) void k_compute_ef(View phi, double *__restrict
     }
 }
 
-// The same operator, one thread per node, for columns [kbeg, nk) of planes r: the few columns
-// the marching kernel leaves over.  Every operand is a plain load.
-__global__ __launch_bounds__(256) void k_compute_ef_columns(View phi, double *__restrict__ ef, int64_t ef_i0,
-                                                            int64_t ni, int64_t kbeg, Coef hx, Coef hy, Coef hz,
-                                                            IRange r)
-{
-    const int64_t nj = phi.d[1], nk = phi.d[2];
-    const int64_t ncol = nk - kbeg;
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= nj * ncol) return;
-    const int64_t k = kbeg + t % ncol, j = t / ncol, i = r.lo + blockIdx.y;
-    const double *p = phi.p;
-    auto at = [&](int64_t a, int64_t b, int64_t c) { return p[phi.at(a, b, c)]; };
-    const double c0 = at(i, j, k);
-    // offsets -2..+2 along each axis, clamped where the one-sided case does not read them
-    auto axis = [&](int a, int64_t pos, int64_t last, const Coef &h) {
-        auto v = [&](int64_t s) {
-            const int64_t q = clampi(pos + s, 0, last);
-            return a == 0 ? at(q, j, k) : (a == 1 ? at(i, q, k) : at(i, j, q));
-        };
-        return ef_axis(v(-2), v(-1), c0, v(1), v(2), pos, last, h);
-    };
-    double *out = ef + (((i - ef_i0) * nj + j) * nk + k) * 3;
-    out[0] = axis(0, i, ni - 1, hx);
-    out[1] = axis(1, j, nj - 1, hy);
-    out[2] = axis(2, k, nk - 1, hz);
-}
-
 }  // namespace
 
 void compute_ef(hipStream_t s, View phi, double *ef, int64_t ef_i0, const int64_t n[3], const double dh[3],
                 IRange r)
 {
     if (r.hi <= r.lo) return;
-    // measured at 513^3: 2 rows per lane 13 % slower than 4 (more halo rows per owned row); 8 do not
-    // fit the register file at two waves per SIMD
+    // measured at 513^3: 2 rows per lane (four waves per SIMD instead of two) 7 % slower than 4 (more
+    // halo rows per owned row); 8 do not fit the register file at two waves per SIMD
     constexpr int JR = 4;
     const int rows = 4 * JR;
     // columns left after the last full window go to the per-node kernel when they are few
@@ -242,16 +278,13 @@ void compute_ef(hipStream_t s, View phi, double *ef, int64_t ef_i0, const int64_
     const bool blocked = wg_order_blocked();
     g.chunks = pick_chunks((int64_t)g.ktiles * g.jtiles, planes, 3, 1, 512, !blocked);
     g.ci = (planes + g.chunks - 1) / g.chunks;
+    // one more workgroup per plane, after the marching ones, when columns are left over
+    const unsigned col_wgs = kmain < n[2] ? (unsigned)planes : 0u;
     const WgOrder order{g.ktiles * g.jtiles * g.chunks, blocked ? 1 : 0};
     const Coef hx = make_coef(0, 0, 0, 2 * dh[0]), hy = make_coef(0, 0, 0, 2 * dh[1]),
                hz = make_coef(0, 0, 0, 2 * dh[2]);
-    hipLaunchKernelGGL((k_compute_ef<JR>), dim3(order.grid()), dim3(256), 0, s, phi, ef, ef_i0, n[0], kmain, hx, hy,
+    hipLaunchKernelGGL((k_compute_ef<JR>), dim3(order.grid() + col_wgs), dim3(256), 0, s, phi, ef, ef_i0, n[0], kmain, hx, hy,
                        hz, r, g, order);
-    if (kmain < n[2]) {
-        const int64_t per_plane = n[1] * (n[2] - kmain);
-        hipLaunchKernelGGL(k_compute_ef_columns, dim3((unsigned)((per_plane + 255) / 256), (unsigned)planes), dim3(256),
-                           0, s, phi, ef, ef_i0, n[0], kmain, hx, hy, hz, r);
-    }
 }
 
 }  // namespace mgk

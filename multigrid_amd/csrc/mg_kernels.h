@@ -61,7 +61,7 @@ inline int pick_chunks(int64_t tiles, int64_t planes, int extra, int align = 1, 
 struct WgOrder {
     int total;    // chunks x windows
     int blocked;  // 1: XCD-blocked order; 0: plain index (chunk fastest)
-    unsigned grid() const { return blocked ? 8u * (unsigned)((total + 7) / 8) : (unsigned)total; }
+    __host__ __device__ unsigned grid() const { return blocked ? 8u * (unsigned)((total + 7) / 8) : (unsigned)total; }
 #if defined(__HIPCC__)
     __device__ int item(unsigned b) const
     {

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""Times mg_compute_ef on the device-resident 513^3 potential (HIP events inside the library)."""
+"""Times mg_compute_ef on the device-resident 513^3 potential (HIP events inside the library).
+usage: ef_time.py [n] [path of another build of libmg_hip.so to time instead]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multigrid_amd import libmg, problem
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 513
+if len(sys.argv) > 2:
+    libmg.LIB_PATH = os.path.abspath(sys.argv[2])
 N = (n, n, n)
 h = libmg.Handle(N, problem.main_extents_dh(N), 0)
 h.set_phi(np.random.default_rng(1).random(N))
