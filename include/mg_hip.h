@@ -366,6 +366,10 @@ int mg_dev_compute_ef(void *stream, const mg_dev_array *phi, void *ef, int64_t e
 #define MG_UNIQUE_ID_BYTES 128
 #define MG_TRANSPORT_RCCL 0
 #define MG_TRANSPORT_LOCAL 1
+/* No transfers at all: ONE rank of a world of `world` ranks, alone, running exactly the launches
+ * and stream dependencies it would run there (halo planes keep what they hold, sums stay local:
+ * the results mean nothing).  For timing one rank's share of a partitioned solve on one GPU. */
+#define MG_TRANSPORT_NONE 2
 typedef struct mg_dist mg_dist;
 typedef struct mg_local_group mg_local_group;
 typedef struct mg_dist_config {

@@ -243,7 +243,12 @@ struct RcclTransport : Transport {
         static_assert(sizeof(ncclUniqueId) == MG_UNIQUE_ID_BYTES, "unique id size");
         ncclUniqueId id;
         memcpy(&id, id_bytes, sizeof(id));
-        HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        // Highest priority: a transfer is started while the interior launch of the same sweep is
+        // queued right behind it on the kernel stream, and that launch fills every CU for its whole
+        // run; RCCL's few workgroups must be placed first, not after it.
+        int prio_least = 0, prio_greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, prio_greatest));
         HIP_TRY(hipEventCreateWithFlags(&to_cs, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&from_cs, hipEventDisableTiming));
         NCCL_TRY(api->CommInitRank(&comm, world, id, rank));
@@ -512,6 +517,25 @@ struct LocalTransport : Transport {
     {
         if (world == 1) return copy_planes(mine, full->v, p.stored(l, eps, 0, halo), compute);
         return guard(scatter_now(p, l, eps, full, mine, halo, compute));
+    }
+};
+
+// ---- no transfers: ONE rank of a larger world, alone on its GPU, for timing that rank's share
+//
+// Every launch, its plane ranges and the order of the streams' dependencies are those of the rank
+// in the full world; halo planes keep whatever they hold and the sums stay local, so the numbers
+// a solve produces mean nothing.
+struct SoloTransport : Transport {
+    int start(Slab &, IRange, int, hipStream_t) override { return MG_OK; }
+    int finish(Slab &, hipStream_t) override { return MG_OK; }
+    int allreduce(double *, hipStream_t) override { return MG_OK; }
+    int gather(const Plan &p, int l, bool eps, const Slab &mine, Slab *full, hipStream_t compute) override
+    {
+        return rank == 0 ? copy_planes(*full, mine.v, p.own(l, eps, 0), compute) : MG_OK;
+    }
+    int scatter(const Plan &p, int l, bool eps, const Slab *full, Slab &mine, int halo, hipStream_t compute) override
+    {
+        return rank == 0 ? copy_planes(mine, full->v, p.stored(l, eps, 0, halo), compute) : MG_OK;
     }
 };
 
@@ -886,7 +910,8 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
         if (base.nu[l] < 0 || base.nu[l] > 100000) FAIL(MG_ERR_INVALID, "nu[%d]=%d out of range", l, base.nu[l]);
     if (cfg->transport == MG_TRANSPORT_LOCAL && cfg->world > 1 && (!cfg->local_group || cfg->local_group->world != cfg->world))
         FAIL(MG_ERR_INVALID, "the in-process transport needs an mg_local_group of the same world size");
-    if (cfg->transport != MG_TRANSPORT_LOCAL && cfg->transport != MG_TRANSPORT_RCCL) FAIL(MG_ERR_INVALID, "unknown transport %d", cfg->transport);
+    if (cfg->transport != MG_TRANSPORT_LOCAL && cfg->transport != MG_TRANSPORT_RCCL && cfg->transport != MG_TRANSPORT_NONE)
+        FAIL(MG_ERR_INVALID, "unknown transport %d", cfg->transport);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) FAIL(MG_ERR_NO_DEVICE, "no HIP device visible");
     if (base.device < 0 || base.device >= count) FAIL(MG_ERR_INVALID, "device %d out of range (have %d)", base.device, count);
@@ -935,6 +960,15 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
         }
         d->tr = t;
         CREATE_TRY(t->init(cfg->rank, cfg->world, cfg->unique_id));
+    } else if (cfg->transport == MG_TRANSPORT_NONE) {
+        SoloTransport *t = new (std::nothrow) SoloTransport();
+        if (!t) {
+            mg_dist_destroy(d);
+            FAIL(MG_ERR_NOMEM, "host allocation failed");
+        }
+        t->rank = cfg->rank;
+        t->world = cfg->world;
+        d->tr = t;
     } else {
         LocalTransport *t = new (std::nothrow) LocalTransport();
         if (!t) {

@@ -10,13 +10,14 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmg_hip.so")
+# MG_HIP_LIB names another build of the library (used to time two builds side by side)
+LIB_PATH = os.environ.get("MG_HIP_LIB") or os.path.join(_HERE, "libmg_hip.so")
 
 MG_MAX_LEVELS = 12
 MG_ABI_VERSION = 2
 MG_MAX_GPUS = 16
 MG_UNIQUE_ID_BYTES = 128
-MG_TRANSPORT_RCCL, MG_TRANSPORT_LOCAL = 0, 1
+MG_TRANSPORT_RCCL, MG_TRANSPORT_LOCAL, MG_TRANSPORT_NONE = 0, 1, 2
 MG_FLAG_KEEP_FINE_RESIDUAL = 1
 MG_FLAG_RESTRICT_7PT = 2
 
@@ -452,7 +453,7 @@ class DistRank:
     same arguments apart from rank and device; creation, vcycles, solve and close are collective."""
 
     def __init__(self, n, dh, depth, rank, world, device=0, unique_id=None, local_group=None, coarse_cut=0,
-                 nu=None, omega=None, overlap=True):
+                 nu=None, omega=None, overlap=True, alone=False):
         self.n = tuple(int(a) for a in n)
         dc = MgDistConfig()
         dc.base = default_config(self.n, dh, depth, device)
@@ -462,7 +463,9 @@ class DistRank:
         if omega is not None:
             dc.base.omega = omega
         dc.rank, dc.world, dc.coarse_cut, dc.no_overlap = rank, world, coarse_cut, int(not overlap)
-        if local_group is not None or (world == 1 and unique_id is None):
+        if alone:
+            dc.transport = MG_TRANSPORT_NONE  # this rank of `world`, without peers: timing only
+        elif local_group is not None or (world == 1 and unique_id is None):
             dc.transport = MG_TRANSPORT_LOCAL
             dc.local_group = local_group._g if local_group is not None else None
         else:

@@ -6,7 +6,11 @@ launches, the coarse tail on rank 0) with a communicator that moves nothing: hal
 their initial zeros, so the numbers mean nothing, the kernels and their launch geometry are the
 real ones.  What is missing from these times is only what the transport adds on a multi-GPU node.
 
-    python tools/slab_rank_time.py [--size 1025] [--cases 8:3,8:0,4:1,2:0] [--cut 4]
+The default driver is the product's one, the C++ rank inside libmg_hip (mg_dist with
+MG_TRANSPORT_NONE), timed as a whole; --python runs the schedule's Python twin
+(multigrid_amd/dist.py) instead, which also times the levels one by one.
+
+    python tools/slab_rank_time.py [--size 1025] [--cases 8:3,8:0,4:1,2:0] [--cut 4] [--python]
 """
 import argparse
 import os
@@ -99,17 +103,34 @@ def measure(n, world, rank, cycles=10, overlap=True, cut=None):
     return out
 
 
+def measure_cxx(n, world, rank, cycles=10, overlap=True, cut=None):
+    """The same share driven by mg_dist (the product's driver): device time of `cycles` cycles."""
+    from multigrid_amd import libmg
+    N = (n, n, n)
+    depth = problem.reference_depth_for(N)
+    d = libmg.DistRank(N, problem.main_extents_dh(N), depth, rank, world, device=0, coarse_cut=cut or 0,
+                       overlap=overlap, alone=True)
+    d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
+    d.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
+    d.vcycles(2)
+    d.vcycles(cycles)
+    out = {"world": world, "rank": rank, "planes": d.own, "cut": d.cut, "cycle_ms": d.stats()["last_ms"] / cycles}
+    d.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=1025)
     ap.add_argument("--cases", default="8:3,8:0,4:1,2:0")
     ap.add_argument("--no-overlap", action="store_true", help="whole-slab launches, no edge/interior split")
     ap.add_argument("--cut", type=int, default=None, help="first level solved whole on rank 0 (default: first with <= 128 planes)")
+    ap.add_argument("--python", action="store_true", help="time the Python twin of the schedule, level by level")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     for case in args.cases.split(","):
         w, r = (int(x) for x in case.split(":"))
-        res = measure(args.size, w, r, overlap=not args.no_overlap, cut=args.cut)
+        res = (measure if args.python else measure_cxx)(args.size, w, r, overlap=not args.no_overlap, cut=args.cut)
         print(" ".join(f"{k}={v:.3f}" if isinstance(v, float) else f"{k}={v}" for k, v in res.items()), flush=True)
 
 
