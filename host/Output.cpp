@@ -40,6 +40,7 @@ bool Output::fields(World &world, const std::string &path)
     out << "Spacing=\"" << dh[0] << " " << dh[1] << " " << dh[2] << "\" ";
     out << "WholeExtent=\"0 " << world.ni - 1 << " 0 " << world.nj - 1 << " 0 " << world.nk - 1 << "\">\n";
     out << "<PointData>\n";
+    data_array(out, "NodeVol", 1, world.node_vol);
     data_array(out, "phi", 1, world.phi);
     data_array(out, "rho", 1, world.rho);
     data_array(out, "ef", 3, world.ef);

@@ -9,8 +9,9 @@
 #include "World.h"
 
 namespace Output {
-// Writes phi, rho and ef of `world` to `path`.  The reference's file additionally carries node
-// volumes and per-species number densities, which belong to its particle side.  Returns false
+// Writes NodeVol, phi, rho and ef of `world` to `path`, in the reference's order.  The reference's
+// file additionally carries per-species number densities (between rho and ef), which belong to
+// its particle side.  Returns false
 // (after a message on stderr, like the reference) when the file cannot be opened.
 bool fields(World &world, const std::string &path);
 }  // namespace Output

@@ -28,12 +28,17 @@ public:
     const int ni, nj, nk;
     const int3 nn;
 
+    // 0.5 * EPS_0 * sum(|E|^2 * node volume) (cpp/World.cpp:88-100)
+    double getPE();
+
     Field phi;         // potential; Dirichlet values live in its face nodes
     Field rho;         // charge density
+    Field node_vol;    // dh[0]*dh[1]*dh[2], halved per wall the node lies on (cpp/World.cpp:74-85)
     Field3 ef;         // electric field
     FieldI object_id;  // 1 on fixed (Dirichlet) nodes
 
 protected:
+    void computeNodeVolumes();
     double3 x0, dh, xm, xc;
 };
 

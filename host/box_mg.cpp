@@ -5,6 +5,10 @@
 // synthetic charge density used by this repository's benchmarks.
 //
 //   box_mg [n=41] [depth=2] [tol=1e-4] [--b] [--dump file] [--dump-ef file]
+//   --menu asks for the solver on stdin with the reference's two prompts (cpp/Main.cpp:62-107:
+//   `printf '4\n2\n' | box_mg 41 --menu` is the reference's `printf '4\n2\n' | ./box 41`), with
+//   the reference's limits (10000 iterations, tolerance 1e-4); of its menu, (1) Gauss-Seidel and
+//   (4) MultiGrid V1-V5 are this library's solvers, the others are refused;
 //   --b selects the reference's "B" solver variant (7-point restriction);
 //   --vti file writes phi, rho and ef as VTK ImageData in the reference's ASCII format
 //   --gpus 0,1,2,3 splits the grid into slabs over those GPUs (an ordinal may repeat);
@@ -43,7 +47,7 @@ int main(int argc, char **argv)
     int n = 41, depth = 2;
     double tol = 1e-4;
     const char *dump = nullptr, *dump_ef = nullptr, *vti = nullptr;
-    bool variant_b = false, again = false, pageable = false;
+    bool variant_b = false, again = false, pageable = false, menu = false;
     std::vector<int> gpus;
     int pos = 0;
     for (int a = 1; a < argc; a++) {
@@ -51,6 +55,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--dump-ef") && a + 1 < argc) dump_ef = argv[++a];
         else if (!strcmp(argv[a], "--b")) variant_b = true;
         else if (!strcmp(argv[a], "--again")) again = true;
+        else if (!strcmp(argv[a], "--menu")) menu = true;
         else if (!strcmp(argv[a], "--pageable")) pageable = true;
         else if (!strcmp(argv[a], "--gpus") && a + 1 < argc) {
             for (char *t = strtok(argv[++a], ","); t; t = strtok(nullptr, ",")) gpus.push_back(atoi(t));
@@ -61,6 +66,27 @@ int main(int argc, char **argv)
         else if (pos == 2) { tol = atof(argv[a]); pos++; }
     }
     std::cout << "Using mesh size : " << n << "x" << n << "x" << n << std::endl;
+    if (menu) {
+        int choice = 0, choice2 = 0;
+        tol = 1e-4;
+        std::cout << "Choose solver (1)Gauss-Seidel (2)FFT (3)Conjugate Gradient (4)MultiGrid (5) Preconditioned CG : ";
+        std::cin >> choice;
+        if (choice == 4) {
+            std::cout << "MultiGrid V-Cycle size (1)V1 (2)V2 (3)V3 (4)V4 (5)V5: ";
+            std::cin >> choice2;
+            if (choice2 < 1 || choice2 > 5) {
+                std::cout << "Invalid choice using V1 as default \n";
+                choice2 = 1;
+            }
+            depth = choice2;
+        } else if (choice == 2 || choice == 3 || choice == 5) {
+            std::cerr << "box_mg: solver " << choice << " (FFT, CG, PCG) is not part of the multigrid library" << std::endl;
+            return 1;
+        } else {
+            if (choice != 1) std::cout << "Invalid choice using Gauss-Seidel as default \n";
+            depth = 0;
+        }
+    }
     try {
 #ifndef MG_FIELD_ROW_PER_ALLOCATION
         if (!pageable) {
@@ -80,7 +106,7 @@ int main(int argc, char **argv)
                                          (std::sin(pi * x) * std::sin(pi * y) * std::sin(pi * z) +
                                           0.5 * std::sin(5 * pi * x) * std::sin(3 * pi * y) * std::sin(7 * pi * z));
                 }
-        MultiGridSolverHIP *mg = depth == 0       ? new GaussSeidelSolverHIP(world, 100000, tol)
+        MultiGridSolverHIP *mg = depth == 0       ? new GaussSeidelSolverHIP(world, menu ? 10000 : 100000, tol)
                                  : gpus.size() > 1 ? new MultiGridSolverHIP(world, 10000, tol, depth, gpus)
                                                    : new MultiGridSolverHIP(world, 10000, tol, depth, 0, variant_b);
         PotentialSolver *solver = mg;  // used through the base pointer, like the reference driver

@@ -100,6 +100,25 @@ def test_solve_through_potential_solver_interface(box, gpu, orc, tmp_path, n, de
 
 
 @pytest.mark.gpu
+def test_reference_menu_on_stdin(box, gpu, orc, tmp_path):
+    """`printf '4\\n2\\n' | box_mg 41 --menu` is the reference's `printf '4\\n2\\n' | ./box 41`
+    (cpp/Main.cpp:62-107): MultiGridSolverV2(world, 10000, 1e-4).  The cycle count and the potential
+    equal the oracle's red-black solve at that tolerance; the menu's other solvers are refused."""
+    n = 41
+    out = tmp_path / "phi.bin"
+    p = subprocess.run([box, str(n), "--menu", "--dump", str(out)], input="4\n2\n", capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "Choose solver (1)Gauss-Seidel" in p.stdout and "MultiGrid V-Cycle size (1)V1" in p.stdout
+    N = (n, n, n)
+    ref = np.zeros(N)
+    ok, cycles, _, _ = orc.Solver(N, orc.main_extents_dh(N), 2).solve(ref, orc.synthetic_rho(N), 10000, 1e-4, rb=True)
+    assert ok and f"converged=1 cycles={cycles} " in p.stdout
+    assert rel_l2(np.fromfile(out).reshape(N), ref) <= 1e-9
+    p = subprocess.run([box, "21", "--menu"], input="2\n", capture_output=True, text=True)
+    assert p.returncode == 1 and "not part of the multigrid library" in p.stderr
+
+
+@pytest.mark.gpu
 def test_gauss_seidel_and_field_through_the_interface(box, gpu, orc, tmp_path):
     """depth 0 = GaussSeidelSolver behind the same base pointer; computeEF() is answered from the
     device-resident potential and must equal the host formula applied to the returned phi."""
@@ -152,7 +171,10 @@ def test_vti_writer_format(tmp_path):
     comps, lines = arrays["ef"]
     assert comps == 3 and len(lines) == nk
     assert lines[2].reshape(nj, ni, 3)[3, 1].tolist() == [1.0, 3.0, 2.0]
-    assert list(arrays) == ["phi", "rho", "ef"]
+    assert list(arrays) == ["NodeVol", "phi", "rho", "ef"]  # the reference's order, without its per-species densities
+    comps, lines = arrays["NodeVol"]
+    cell = 0.2 * 0.1 * 0.1
+    assert comps == 1 and np.isclose(lines[0][0], cell / 8) and np.isclose(lines[2][1 * ni + 1], cell)
 
 
 @pytest.mark.gpu
