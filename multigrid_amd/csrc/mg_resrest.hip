@@ -53,7 +53,15 @@ __device__ __forceinline__ double wave_sum64(double v)
 
 // WJ x 2*WKP window of fine points; residual valid on the window minus one ring;
 // owned (norm, restriction centres) = window minus two rings.
-template <int WJ, int WKP, int D, bool STORE_RF, int NT>
+//
+// GS: the convergence test of the plain Gauss-Seidel/SOR solver instead (reference
+// GaussSeidelSolver::solve, cpp/PotentialSolver.cpp:267-286) -- the same march over phi and the
+// right-hand side, with
+//   R = -phi*d + rho/EPS_0 + cx*(phi[i-1]+phi[i+1]) + cy*(phi[j-1]+phi[j+1]) + cz*(phi[k-1]+phi[k+1])
+// evaluated left to right (opposite sign and another association than the multigrid residual),
+// squares summed over the INTERIOR nodes only, and nothing else: no residual planes in LDS, no
+// restriction, no barrier in the plane loop.
+template <int WJ, int WKP, int D, bool STORE_RF, int NT, bool GS = false>
 __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View Rf, View Rc, int nI,
                                                            Coef c, double *__restrict__ partials,
                                                            int CI, int nchunks, int tiles_k, int rlo,
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
     constexpr int Q = WJ / G;      // adjacent rows per lane
     constexpr int TJ = WJ - 4, TK = WK - 4;   // owned fine rows / columns (even)
     constexpr int TJC = TJ / 2, TKC = TK / 2; // coarse outputs per tile and coarse plane
-    __shared__ double ring[3][WJ][WK];
+    __shared__ double ring[GS ? 1 : 3][GS ? 1 : WJ][WK];
     __shared__ double red[NT / 64];
 
     const int tid = threadIdx.x;
@@ -137,7 +145,27 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
             hNf[K] = load(phi, pb, -1);
             hSf[K] = load(phi, pb, Q);
 
-            if (p >= 0) {
+            if constexpr (GS) {
+                if (p >= ia && p >= 1 && p <= nI - 2) {
+#pragma unroll
+                    for (int q = 0; q < Q; q++) {
+                        const int r = row_of(q);
+                        const int j = j0 + r;
+                        const d2 u = u0[q];
+                        const d2 un = q == 0 ? hN0 : u0[q > 0 ? q - 1 : 0];
+                        const d2 us = q == Q - 1 ? hS0 : u0[q < Q - 1 ? q + 1 : Q - 1];
+                        const double left = lane_left(u.y);
+                        const double right = lane_right(u.x);
+                        const double rx = -u.x * c.d + b0[q].x + c.cx * (um1[q].x + up1[q].x) + c.cy * (un.x + us.x) +
+                                          c.cz * (left + u.y);
+                        const double ry = -u.y * c.d + b0[q].y + c.cx * (um1[q].y + up1[q].y) + c.cy * (un.y + us.y) +
+                                          c.cz * (u.x + right);
+                        const bool own = r >= 2 && r <= WJ - 3 && m >= 1 && m <= WKP - 2 && j >= 1 && j <= nJ - 2;
+                        if (own && kk >= 1 && kk <= nK - 2) acc += rx * rx;
+                        if (own && kk + 1 <= nK - 2) acc += ry * ry;
+                    }
+                }
+            } else if (p >= 0) {
                 double(*S)[WK] = ring[p % 3];
                 const bool iface = p == 0 || p == nI - 1;
                 const bool iown = p >= ia;
@@ -172,9 +200,9 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
                     }
                 }
             }
-            __syncthreads();
+            if constexpr (!GS) __syncthreads();
             // ---- one plane of R_2h from residual planes p-2, p-1, p ---------
-            if ((p & 1) && p >= ia + 1) {
+            if (!GS && (p & 1) && p >= ia + 1) {
                 const int I = (p - 1) >> 1;
                 if (I < cI) {
                     double(*A)[WK] = ring[(p - 2 + 3) % 3];  // plane 2I-1
@@ -322,6 +350,24 @@ void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const 
         else LAUNCHW(32, 2, false, 256);
     }
 #undef LAUNCHW
+}
+
+// Convergence test of the Gauss-Seidel solver: partials[0..gs_residual_partials) = per-workgroup
+// sums of R^2 over the interior nodes of planes r (see k_residual_restrict, GS).
+int64_t gs_residual_partials(const int64_t n[3], IRange r) { return r.hi > r.lo ? geometry(n, r).grid : 0; }
+
+void gs_residual_sumsq(hipStream_t s, View phi, View b, const int64_t n[3], Coef c, double *partials, IRange r)
+{
+    if (r.hi <= r.lo) return;
+    const Geometry g = geometry(n, r);
+    View none = phi;
+    none.p = nullptr;
+#define LAUNCHG(WJ, NT)                                                                                          \
+    hipLaunchKernelGGL((k_residual_restrict<WJ, 32, 2, false, NT, true>), dim3(g.order.grid()), dim3(NT), 0, s, phi, \
+                       b, none, none, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi, g.order)
+    if (window_rows(n) == 64) LAUNCHG(64, 512);
+    else LAUNCHG(32, 256);
+#undef LAUNCHG
 }
 
 }  // namespace mgk
