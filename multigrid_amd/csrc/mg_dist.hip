@@ -707,14 +707,19 @@ struct mg_dist {
             TRY(sweeps(0, nullptr, false));
         }
         const IRange o = own(0, false);
-        IRange edges[2], inner, parts[3];
+        IRange edges[2], inner, parts[2], parts2[2] = {IRange{0, 0}, IRange{0, 0}};
         int n_edges, n_parts = 0, wait_at = 0;
         split(o, edges, &n_edges, &inner);
         // slab boundaries are multiples of 2^cut, so every range below starts on an even plane
         if (world > 1 && overlap && inner.hi - inner.lo >= 2 * H_U) {
-            // the interior needs no halo plane: it runs while the last sweep's exchange completes
+            // the interior needs no halo plane: it runs while the last sweep's exchange completes;
+            // the planes next to both neighbours follow in ONE launch
             parts[n_parts++] = inner;
-            for (int e = 0; e < n_edges; e++) parts[n_parts++] = edges[e];
+            if (n_edges > 0) {
+                parts[n_parts] = edges[0];
+                if (n_edges == 2) parts2[n_parts] = edges[1];
+                n_parts++;
+            }
             wait_at = 1;
         } else {
             parts[n_parts++] = o;
@@ -724,9 +729,10 @@ struct mg_dist {
         none.p = nullptr;
         for (int idx = 0; idx < n_parts; idx++) {
             if (idx == wait_at) TRY(tr->finish(phi, stream));
-            const int64_t np = mgk::residual_restrict_partials(plan.n0, parts[idx]);
+            const int64_t np = mgk::residual_restrict_partials(plan.n0, parts[idx], parts2[idx]);
             if (used + np > n_partials) FAIL(MG_ERR_STATE, "partial-sum buffer too small");
-            mgk::residual_restrict(stream, phi.v, b.v, none, R[1].v, plan.n0, c[0], partials + used, parts[idx]);
+            mgk::residual_restrict(stream, phi.v, b.v, none, R[1].v, plan.n0, c[0], partials + used, parts[idx],
+                                   parts2[idx]);
             used += np;
         }
         mgk::sum_partials(stream, partials, used, d_sum);
@@ -1004,7 +1010,7 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
         d->split(o, edges, &n_edges, &inner);
         int64_t need = mgk::residual_restrict_partials(P.n0, o);
         int64_t parts = inner.hi > inner.lo ? mgk::residual_restrict_partials(P.n0, inner) : 0;
-        for (int e = 0; e < n_edges; e++) parts += mgk::residual_restrict_partials(P.n0, edges[e]);
+        if (n_edges > 0) parts += mgk::residual_restrict_partials(P.n0, edges[0], n_edges == 2 ? edges[1] : IRange{0, 0});
         d->n_partials = need > parts ? need : parts;
         CREATE_TRY(hip_ok(hipMalloc((void **)&d->partials, (size_t)(d->n_partials + 1) * sizeof(double)), "hipMalloc(partials)"));
         d->blocks.push_back(d->partials);

@@ -205,9 +205,10 @@ void residual(hipStream_t s, View phi, View b, View R, const int64_t n[3], Coef 
 // Fused residual + sum of squares + restriction: coarse planes [r.lo/2, ...) of
 // Rc = restrict27(residual(phi, b)) for fine planes r (r.lo even); the fine residual is
 // written only when Rf.p is non-null.  phi must hold planes [r.lo-2, r.hi+1).
-int64_t residual_restrict_partials(const int64_t n[3], IRange r);
+// A non-empty r2 (same length as r, disjoint, above it, r2.lo even) goes through the same launch.
+int64_t residual_restrict_partials(const int64_t n[3], IRange r, IRange r2 = IRange{0, 0});
 void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const int64_t n[3], Coef c,
-                       double *partials, IRange r);
+                       double *partials, IRange r, IRange r2 = IRange{0, 0});
 // out[0] = sum of partials[0..count) in a fixed order.
 void sum_partials(hipStream_t s, const double *partials, int64_t count, double *out);
 // partial sums of x^2 over a flat array

@@ -65,7 +65,7 @@ template <int WJ, int WKP, int D, bool STORE_RF, int NT, bool GS = false>
 __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View Rf, View Rc, int nI,
                                                            Coef c, double *__restrict__ partials,
                                                            int CI, int nchunks, int tiles_k, int rlo,
-                                                           int rhi, WgOrder order)
+                                                           int rhi, WgOrder order, int cstride)
 {
     static_assert(WKP == 32, "row shuffles assume 32 lanes per row");
     constexpr int WK = 2 * WKP;
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
     const int j0 = tj * TJ - 2, k0 = tk * TK - 2;
     const int nJ = (int)phi.d[1], nK = (int)phi.d[2];
     const int cI = nI >> 1, cJ = (int)Rc.d[1], cK = (int)Rc.d[2];
-    const int ia = rlo + chunk * CI;
+    // chunks are CI planes long and start cstride planes apart (cstride == CI: one contiguous range)
+    const int ia = rlo + chunk * cstride;
     const int ib = min(ia + CI, rhi);
     double acc = 0.0;
     if (ia < ib) {
@@ -297,17 +298,19 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
     }
 }
 
-struct Geometry {
-    int tiles_j, tiles_k, nchunks, CI;
-    WgOrder order;
-    unsigned grid;  // = order.total: workgroups that do work, and partial sums written
-};
-
 // window rows: 32 (256 threads) or 64 (512 threads; fewer halo rows re-read per owned row, pays
 // once a plane has enough windows to fill the chip).
 int window_rows(const int64_t n[3]) { return n[1] >= 256 ? 64 : 32; }
 
-Geometry geometry(const int64_t n[3], IRange r)
+struct Geometry {
+    int tiles_j, tiles_k, nchunks, CI, cstride, rhi;
+    WgOrder order;
+    unsigned grid;  // = order.total: workgroups that do work, and partial sums written
+};
+
+// r2 non-empty: two short ranges of equal length in one launch (the planes next to either slab
+// neighbour), one chunk each.
+Geometry geometry(const int64_t n[3], IRange r, IRange r2 = IRange{0, 0})
 {
     const int TJ = window_rows(n) - 4, TK = 60;
     Geometry g;
@@ -315,31 +318,40 @@ Geometry geometry(const int64_t n[3], IRange r)
     g.tiles_j = (int)((n[1] + TJ - 1) / TJ);
     g.tiles_k = (int)((n[2] + TK - 1) / TK);
     const bool blocked = wg_order_blocked();
-    int nchunks = pick_chunks((int64_t)g.tiles_j * g.tiles_k, planes, 3, 2, window_rows(n) == 64 ? 256 : 512,
-                              !blocked);
-    int CI = (int)((planes + nchunks - 1) / nchunks);
-    CI += CI & 1;  // chunks start on even planes: a coarse plane's three fine planes stay together
-    g.nchunks = nchunks;
-    g.CI = CI;
-    g.grid = (unsigned)(nchunks * g.tiles_j * g.tiles_k);
+    if (r2.hi > r2.lo) {
+        g.nchunks = 2;
+        g.CI = (int)planes;
+        g.cstride = (int)(r2.lo - r.lo);
+        g.rhi = (int)r2.hi;
+    } else {
+        int nchunks = pick_chunks((int64_t)g.tiles_j * g.tiles_k, planes, 3, 2, window_rows(n) == 64 ? 256 : 512,
+                                  !blocked);
+        int CI = (int)((planes + nchunks - 1) / nchunks);
+        CI += CI & 1;  // chunks start on even planes: a coarse plane's three fine planes stay together
+        g.nchunks = nchunks;
+        g.CI = CI;
+        g.cstride = CI;
+        g.rhi = (int)r.hi;
+    }
+    g.grid = (unsigned)(g.nchunks * g.tiles_j * g.tiles_k);
     g.order = WgOrder{(int)g.grid, blocked ? 1 : 0};
     return g;
 }
 
 }  // namespace
 
-int64_t residual_restrict_partials(const int64_t n[3], IRange r) { return geometry(n, r).grid; }
+int64_t residual_restrict_partials(const int64_t n[3], IRange r, IRange r2) { return geometry(n, r, r2).grid; }
 
 // Coarse planes of R_c = restrict27(residual(phi, b)) for the fine planes r (r.lo even), and
 // partials[0..residual_restrict_partials) = per-workgroup sums of squares of the fine residual
 // over planes r.  Rf.p may be null (the fine residual is then never written).
 void residual_restrict(hipStream_t s, View phi, View b, View Rf, View Rc, const int64_t n[3], Coef c,
-                       double *partials, IRange r)
+                       double *partials, IRange r, IRange r2)
 {
-    const Geometry g = geometry(n, r);
+    const Geometry g = geometry(n, r, r2);
 #define LAUNCHW(WJ, D, RF, NT)                                                                        \
     hipLaunchKernelGGL((k_residual_restrict<WJ, 32, D, RF, NT>), dim3(g.order.grid()), dim3(NT), 0, s, phi, b, \
-                       Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi, g.order)
+                       Rf, Rc, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, g.rhi, g.order, g.cstride)
     // Measured and not built any more: prefetch depths 1 and 3, 512 threads on the 32-row window, and
     // 1024 threads (two rows per lane) on the 64-row window (+10 %).
     if (window_rows(n) == 64) {
@@ -364,7 +376,7 @@ void gs_residual_sumsq(hipStream_t s, View phi, View b, const int64_t n[3], Coef
     none.p = nullptr;
 #define LAUNCHG(WJ, NT)                                                                                          \
     hipLaunchKernelGGL((k_residual_restrict<WJ, 32, 2, false, NT, true>), dim3(g.order.grid()), dim3(NT), 0, s, phi, \
-                       b, none, none, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, (int)r.hi, g.order)
+                       b, none, none, (int)n[0], c, partials, g.CI, g.nchunks, g.tiles_k, (int)r.lo, g.rhi, g.order, g.cstride)
     if (window_rows(n) == 64) LAUNCHG(64, 512);
     else LAUNCHG(32, 256);
 #undef LAUNCHG
