@@ -156,3 +156,37 @@ def test_rccl_transport_in_a_world_of_one(gpu, orc):
     assert (ok, cycles) == (w_ok, w_cyc) and lo == 0
     assert l2 == pytest.approx(w_l2, rel=1e-12)
     assert_bit_equal(phi, want, "phi through the RCCL transport")
+
+
+def test_a_rank_alone_runs_its_share_of_a_larger_world(gpu):
+    """MG_TRANSPORT_NONE: rank 1 and rank 0 of a world of four, each without peers, run the launches
+    of their share (every transfer skipped) and return; the plan is that of the full world.  A
+    world of one through the same transport moves nothing either way, so it still equals the
+    single-GPU handle."""
+    from multigrid_amd import problem
+    n, depth = 129, 3
+    N = (n, n, n)
+    dh = problem.main_extents_dh(N)
+    for rank, own in ((1, (32, 64)), (0, (0, 32))):
+        d = gpu.DistRank(N, dh, depth, rank, 4, device=0, coarse_cut=2, alone=True)
+        try:
+            assert d.own == own and d.cut == 2
+            d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
+            d.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
+            assert np.isfinite(d.vcycles(2))
+            assert d.stats()["bytes_sent"] == 0 and d.stats()["last_ms"] > 0
+        finally:
+            d.close()
+    d = gpu.DistRank(N, dh, depth, 0, 1, device=0, alone=True)
+    try:
+        d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
+        d.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
+        l2 = d.vcycles(2)
+        _, phi = d.get_phi_owned()
+    finally:
+        d.close()
+    with gpu.Handle(N, dh, depth) as h:
+        h.set_rho(problem.synthetic_rho(N))
+        h.set_phi(np.zeros(N))
+        assert h.vcycles(2) == pytest.approx(l2, rel=1e-12)
+        assert_bit_equal(phi, h.get_phi(), "phi of a world of one without transport")
