@@ -325,6 +325,11 @@ def run_distributed(args):
     import numpy as np
     from multigrid_amd import libmg, problem
 
+    # MG_BENCH_FORCE_DIST=1 without a launcher: a world of one rank through the same code
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     world = int(os.environ["WORLD_SIZE"])
