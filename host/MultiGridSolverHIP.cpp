@@ -85,6 +85,9 @@ void MultiGridSolverHIP::init(int depth, int device, bool variant_b, const std::
     if (variant_b) check(mg_default_config_b(&cfg, world.ni, world.nj, world.nk, h, depth), "mg_default_config_b");
     else check(mg_default_config(&cfg, world.ni, world.nj, world.nk, h, depth), "mg_default_config");
     cfg.device = device;
+    // computeEF() follows every solve() in the reference's loop: its array is part of the handle from
+    // the start, not an allocation inside the first call
+    if (devices.size() <= 1) cfg.flags |= MG_FLAG_RESERVE_EF;
     if (devices.size() > 1) {
         cfg.n_gpus = int(devices.size());
         for (std::size_t g = 0; g < devices.size(); g++) cfg.devices[g] = devices[g];

@@ -89,6 +89,10 @@ typedef struct mg_config {
  * of the 27-point full weighting.  The cycle then runs the separate residual and
  * restriction kernels (R_h is stored). */
 #define MG_FLAG_RESTRICT_7PT 2
+/* Allocate the electric field's device array (3 doubles per node) in mg_create instead of in the
+ * first mg_compute_ef, for callers that follow every solve with computeEF() (cpp/Main.cpp:124-126,
+ * :157-166) and time or capture that call.  Single-GPU handles. */
+#define MG_FLAG_RESERVE_EF 4
 
 /* Accumulated device time per operator, measured with HIP events on the
  * handle's stream while profiling is on (mg_set_profiling).  Index with

@@ -503,7 +503,7 @@ int mg_create(const mg_config *cfg, mg_handle **out)
     }
     for (int l = 0; l <= L; l++)
         if (cfg->nu[l] < 0 || cfg->nu[l] > 100000) return fail(MG_ERR_INVALID, "nu[%d]=%d out of range", l, cfg->nu[l]);
-    if (cfg->flags & ~(MG_FLAG_KEEP_FINE_RESIDUAL | MG_FLAG_RESTRICT_7PT))
+    if (cfg->flags & ~(MG_FLAG_KEEP_FINE_RESIDUAL | MG_FLAG_RESTRICT_7PT | MG_FLAG_RESERVE_EF))
         return fail(MG_ERR_INVALID, "unknown flag bits 0x%x", (unsigned)cfg->flags);
     int rc = select_device(cfg->device);
     if (rc) return rc;
@@ -559,6 +559,8 @@ int mg_create(const mg_config *cfg, mg_handle **out)
         if (gs > h->n_partials) h->n_partials = gs;
     }
     CREATE_TRY(hip_try(hipMalloc((void **)&h->partials, (size_t)h->n_partials * sizeof(double)), "hipMalloc(partials)"));
+    if (cfg->flags & MG_FLAG_RESERVE_EF)
+        CREATE_TRY(hip_try(hipMalloc((void **)&h->ef, (size_t)count3(h->lv[0].n) * 3 * sizeof(double)), "hipMalloc(ef)"));
     CREATE_TRY(hip_try(hipHostMalloc((void **)&h->h_sum, sizeof(double), hipHostMallocMapped), "hipHostMalloc"));
     *h->h_sum = 0;
     CREATE_TRY(hip_try(hipHostGetDevicePointer((void **)&h->d_sum, h->h_sum, 0), "hipHostGetDevicePointer"));

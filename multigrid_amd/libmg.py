@@ -20,6 +20,7 @@ MG_UNIQUE_ID_BYTES = 128
 MG_TRANSPORT_RCCL, MG_TRANSPORT_LOCAL, MG_TRANSPORT_NONE = 0, 1, 2
 MG_FLAG_KEEP_FINE_RESIDUAL = 1
 MG_FLAG_RESTRICT_7PT = 2
+MG_FLAG_RESERVE_EF = 4
 
 TIMER_KINDS = ("smooth_fine", "residual", "restrict", "smooth_coarse", "prolong",
                "prolong_correct", "norm", "ef")

@@ -50,11 +50,14 @@ def test_smoother_extreme_magnitudes(gpu, orc):
         assert_bit_equal(got, want, f"smoother at scale {scale}")
 
 
-def test_compute_ef_on_the_handle_follows_the_solve(gpu, orc):
-    """mg_compute_ef works on the device-resident phi a solve left behind."""
+@pytest.mark.parametrize("flags", [0, 4], ids=["ef_array_on_first_use", "ef_array_reserved"])
+def test_compute_ef_on_the_handle_follows_the_solve(gpu, orc, flags):
+    """mg_compute_ef works on the device-resident phi a solve left behind, with its output array
+    allocated by the first call or, with MG_FLAG_RESERVE_EF, by mg_create."""
+    assert gpu.MG_FLAG_RESERVE_EF == 4
     N = (41, 41, 41)
     dh, rho = orc.main_extents_dh(N), orc.synthetic_rho(N)
-    with gpu.Handle(N, dh, 2) as h:
+    with gpu.Handle(N, dh, 2, flags=flags) as h:
         h.set_rho(rho)
         h.set_phi(np.zeros(N))
         with pytest.raises(gpu.MgError):   # nothing computed yet
