@@ -2,6 +2,8 @@
 marching kernels fall somewhere else for every shape, and so do the switches between kernel
 variants (one workgroup in LDS, colour launches, single-pass sweep, sweep pairs, 32- and 64-row
 windows).  Same bar as the per-operator tests: the oracle's bits."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,10 +13,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _shapes():
-    g = np.random.default_rng(20261111)
+    # MG_FUZZ_SEED / MG_FUZZ_MULT draw other and more shapes for an occasional longer run
+    g = np.random.default_rng(int(os.environ.get("MG_FUZZ_SEED", "20261111")))
+    mult = int(os.environ.get("MG_FUZZ_MULT", "1"))
     out = []
     for lo, hi, count in ((3, 40, 4), (40, 140, 5), (120, 300, 5)):
-        for _ in range(count):
+        for _ in range(count * mult):
             out.append(tuple(int(x) for x in g.integers(lo, hi, size=3)))
     # one long axis each way round (few planes and many rows, many planes and few columns)
     out += [(5, 290, 131), (300, 9, 140), (131, 270, 6)]
