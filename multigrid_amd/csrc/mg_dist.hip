@@ -143,13 +143,38 @@ struct Plan {
         if (cut_ < 1 || cut_ > depth) FAIL(MG_ERR_INVALID, "coarse_cut %d outside 1..depth", cut_);
         cut = cut_;
         const int64_t align = (int64_t)1 << cut;
-        const int64_t base = ((n0[0] - 1) / world) / align * align;
-        if (base < align)
+        const int64_t units = (n0[0] - 1) / align;  // slabs are whole units of 2^cut fine planes
+        const int64_t even = units / world;
+        if (even < 1)
             FAIL(MG_ERR_INVALID, "%lld planes over %d ranks leave fewer than 2^%d fine planes per rank; lower coarse_cut or the rank count",
                  (long long)n0[0], world, cut);
-        bounds.resize(world + 1);
-        for (int r = 0; r < world; r++) bounds[r] = r * base;
+        bounds.assign(world + 1, 0);
         bounds[world] = n0[0];
+        if (world == 1) return MG_OK;
+        // Rank 0 also runs the gathered levels cut..L while the others wait, so it owns fewer units
+        // when a unit is cheap enough for that to shorten the slowest rank's cycle.  Both costs are
+        // estimates from measurements on MI355X (a slab rank's whole cycle per fine point; the
+        // gathered levels, which are launch bound and about the same for every grid): the choice
+        // only shifts work between ranks, never the result.
+        const double t_unit = (double)align * (double)n0[1] * (double)n0[2] * 17e-12;
+        const double t_tail = 60e-6 * (depth - cut + 1) + 20e-6;
+        int64_t relief = 0;
+        double best = (double)even * t_unit + t_tail;
+        for (int64_t r = 1; r <= even / 4; r++) {
+            const int64_t rest = units - (even - r), most = (rest + world - 2) / (world - 1);
+            const double mine = (double)(even - r) * t_unit + t_tail, theirs = (double)most * t_unit;
+            const double cost = mine > theirs ? mine : theirs;
+            if (cost < best * (1 - 1e-9)) {
+                best = cost;
+                relief = r;
+            }
+        }
+        // ranks 1..world-1 share what is left as evenly as whole units allow, the spare units going to
+        // the lower ranks (the last rank also takes the planes beyond the last whole unit)
+        const int64_t first = even - relief, rest = units - first;
+        const int64_t each = rest / (world - 1), spare = rest % (world - 1);
+        bounds[1] = first * align;
+        for (int r = 2; r < world; r++) bounds[r] = bounds[r - 1] + (each + (r - 1 <= spare ? 1 : 0)) * align;
         return MG_OK;
     }
     void level_n(int l, int64_t out[3]) const

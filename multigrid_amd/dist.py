@@ -51,11 +51,33 @@ class SlabPlan:
             raise ValueError("cut level must be in 1..depth")
         self.cut = cut
         align = 1 << cut
-        base = ((self.n0[0] - 1) // self.world) // align * align
-        if base < align:
+        units = (self.n0[0] - 1) // align  # slabs are whole units of 2^cut fine planes
+        even = units // self.world
+        if even < 1:
             raise ValueError(f"{self.n0[0]} planes over {self.world} ranks leave fewer than "
                              f"2^{cut} fine planes per rank; lower the cut level or the rank count")
-        self.bounds = [r * base for r in range(self.world)] + [self.n0[0]]  # fine-plane boundaries
+        W = self.world
+        self.bounds = [0] * W + [self.n0[0]]  # fine-plane boundaries
+        if W == 1:
+            return
+        # Rank 0 also runs the gathered levels cut..L while the others wait: it owns fewer units when
+        # that shortens the slowest rank's cycle (the same estimate as Plan::init in
+        # csrc/mg_dist.hip; it only shifts work between ranks, never the result).
+        t_unit = float(align) * float(self.n0[1]) * float(self.n0[2]) * 17e-12
+        t_tail = 60e-6 * (L - cut + 1) + 20e-6
+        relief, best = 0, float(even) * t_unit + t_tail
+        for r in range(1, even // 4 + 1):
+            rest = units - (even - r)
+            most = (rest + W - 2) // (W - 1)
+            cost = max(float(even - r) * t_unit + t_tail, float(most) * t_unit)
+            if cost < best * (1 - 1e-9):
+                best, relief = cost, r
+        first = even - relief
+        rest = units - first
+        each, spare = divmod(rest, W - 1)
+        self.bounds[1] = first * align
+        for r in range(2, W):
+            self.bounds[r] = self.bounds[r - 1] + (each + (1 if r - 1 <= spare else 0)) * align
 
     def level_n(self, l):
         return tuple(a >> l for a in self.n0)

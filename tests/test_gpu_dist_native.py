@@ -167,10 +167,13 @@ def test_a_rank_alone_runs_its_share_of_a_larger_world(gpu):
     n, depth = 129, 3
     N = (n, n, n)
     dh = problem.main_extents_dh(N)
-    for rank, own in ((1, (32, 64)), (0, (0, 32))):
+    from multigrid_amd.dist import SlabPlan
+    plan = SlabPlan(N, depth, 4, cut=2)  # the Python twin's arithmetic: both drivers cut the grid alike
+    assert plan.bounds[1] < plan.bounds[2] - plan.bounds[1]  # rank 0 owns less: it also runs the gathered levels
+    for rank in (1, 0):
         d = gpu.DistRank(N, dh, depth, rank, 4, device=0, coarse_cut=2, alone=True)
         try:
-            assert d.own == own and d.cut == 2
+            assert d.own == plan.own(0, "phi", rank) and d.cut == 2
             d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
             d.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
             assert np.isfinite(d.vcycles(2))
