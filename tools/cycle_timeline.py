@@ -3,11 +3,13 @@
 (the cycle before the last complete one)."""
 import csv
 import glob
+import re
 import sys
 
 f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "k_residual_restrict" in r["Kernel_Name"] or "k_fine_fused" in r["Kernel_Name"]]
+# the V-cycle's fused residual kernel (its last template argument, true, is the Gauss-Seidel solver's norm)
+marks = [i for i, r in enumerate(rows) if re.search(r"k_residual_restrict<[^>]*false>\(", r["Kernel_Name"])]
 a, b = marks[-3], marks[-2]
 t0 = int(rows[a]["Start_Timestamp"])
 for r in rows[a:b + 1]:
