@@ -268,7 +268,7 @@ void compute_ef(hipStream_t s, View phi, double *ef, int64_t ef_i0, const int64_
     // halo rows per owned row); 8 do not fit the register file at two waves per SIMD
     constexpr int JR = 4;
     const int rows = 4 * JR;
-    // columns left after the last full window go to the per-node kernel when they are few
+    // columns left after the last full window are taken node by node (extra workgroups) when they are few
     const int64_t rem = n[2] % EF_COLS;
     const int64_t kmain = (n[2] > EF_COLS && rem != 0 && rem <= 4) ? n[2] - rem : n[2];
     EfGeom g;
