@@ -138,6 +138,13 @@ int mg_default_config(mg_config *cfg, int64_t ni, int64_t nj, int64_t nk,
 int mg_default_config_b(mg_config *cfg, int64_t ni, int64_t nj, int64_t nk,
                         const double dh[3], int depth);
 int mg_create(const mg_config *cfg, mg_handle **out);
+/* Device memory mg_create(cfg) will allocate, in bytes: the whole set on one GPU, or with
+ * n_gpus > 1 the largest share of any GPU (rank 0's: its slabs plus the whole small levels).
+ * Pure arithmetic, no device needed: for choosing n_gpus before anything is allocated (2049^3
+ * with seven coarse grids: 236 GB on one GPU, 30 GB per GPU on eight).  The field's array of
+ * mg_compute_ef (24 bytes per fine node) is counted only with MG_FLAG_RESERVE_EF.  No counterpart
+ * in the reference, whose Fields live in host memory (cpp/PotentialSolver.h:171-272). */
+int mg_device_bytes(const mg_config *cfg, uint64_t *bytes);
 int mg_destroy(mg_handle *h);
 
 /* world.rho -> device (stored as rho/EPS_0, the only form the path uses;

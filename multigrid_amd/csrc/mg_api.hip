@@ -569,6 +569,52 @@ int mg_create(const mg_config *cfg, mg_handle **out)
     return MG_OK;
 }
 
+int mg_device_bytes(const mg_config *cfg, uint64_t *bytes)
+{
+    if (!cfg || !bytes) return fail(MG_ERR_INVALID, "null argument");
+    const int L = cfg->depth;
+    if (L < 0 || L >= MG_MAX_LEVELS) return fail(MG_ERR_INVALID, "depth %d out of range 0..%d", L, MG_MAX_LEVELS - 1);
+    for (int a = 0; a < 3; a++)
+        if (cfg->n[a] < 3 || cfg->n[a] > kMaxDim || (cfg->n[a] >> L) < 3)
+            return fail(MG_ERR_INVALID, "n[%d]=%lld out of range for depth %d", a, (long long)cfg->n[a], L);
+    if (cfg->n_gpus > 1) {
+        if (cfg->n_gpus > MG_MAX_GPUS) return fail(MG_ERR_INVALID, "n_gpus %d exceeds %d", cfg->n_gpus, MG_MAX_GPUS);
+        const long long n[3] = {cfg->n[0], cfg->n[1], cfg->n[2]};
+        long long most = 0;
+        for (int r = 0; r < cfg->n_gpus; r++) {
+            const long long b = mgk::dist_rank_device_bytes(n, L, cfg->n_gpus, cfg->coarse_cut, r);
+            if (b < 0) return MG_ERR_INVALID;  // the plan's message stands
+            if (b > most) most = b;
+        }
+        *bytes = (uint64_t)most;
+        return MG_OK;
+    }
+    // the allocations of mg_create, as arithmetic (keep the two lists alike)
+    auto view_bytes = [](const int64_t d[3]) { return (uint64_t)make_view(nullptr, d).elems() * sizeof(double); };
+    const bool restrict7 = (cfg->flags & MG_FLAG_RESTRICT_7PT) != 0;
+    const bool fused = L >= 1 && !(cfg->flags & MG_FLAG_KEEP_FINE_RESIDUAL) && !restrict7;
+    uint64_t sum = 0;
+    int64_t n0[3] = {cfg->n[0], cfg->n[1], cfg->n[2]};
+    for (int l = 0; l <= L; l++) {
+        int64_t n[3], en[3];
+        for (int a = 0; a < 3; a++) {
+            n[a] = cfg->n[a] >> l;
+            en[a] = n[a] + 1;
+        }
+        if (l >= 1 || !fused) sum += view_bytes(n);
+        if (l >= 1) sum += 2 * view_bytes(en);
+    }
+    sum += 3 * view_bytes(n0);
+    const IRange all{0, n0[0]};
+    int64_t np = fused ? mgk::residual_restrict_partials(n0, all) : mgk::residual_partials(n0, all);
+    const int64_t gs = mgk::gs_residual_partials(n0, all);
+    if (gs > np) np = gs;
+    sum += (uint64_t)np * sizeof(double);
+    if (cfg->flags & MG_FLAG_RESERVE_EF) sum += (uint64_t)count3(n0) * 3 * sizeof(double);
+    *bytes = sum;
+    return MG_OK;
+}
+
 int mg_destroy(mg_handle *h)
 {
     if (!h) return MG_OK;

@@ -871,6 +871,31 @@ int upload_planes(mg_dist *d, Slab &dst, int64_t lo, int64_t hi, const double *d
 
 }  // namespace
 
+// The allocations of mg_dist_create for one rank, as arithmetic (keep the two lists alike).
+long long mgk::dist_rank_device_bytes(const long long n_[3], int depth, int world, int coarse_cut, int rank)
+{
+    const int64_t n[3] = {n_[0], n_[1], n_[2]};
+    Plan P;
+    if (P.init(n, depth, world, coarse_cut)) return -1;
+    auto bytes = [&](int l, bool eps_kind, IRange st) -> long long {
+        int64_t d[3];
+        P.dims(l, eps_kind, d);
+        return (long long)(st.hi - st.lo) * d[1] * mgk::pitch_for(d[2]) * (long long)sizeof(double);
+    };
+    long long sum = 2 * bytes(0, false, P.stored(0, false, rank, H_U)) + bytes(0, false, P.stored(0, false, rank, H_RHS));
+    for (int l = 1; l <= P.cut; l++) {
+        sum += bytes(l, false, P.stored(l, false, rank, H_RHS));
+        sum += (l < P.cut ? 2 : 1) * bytes(l, true, P.stored(l, true, rank, H_U));
+    }
+    if (rank == 0)
+        for (int l = P.cut; l <= depth; l++)
+            sum += bytes(l, false, IRange{0, P.planes(l, false)}) + 2 * bytes(l, true, IRange{0, P.planes(l, true)});
+    const IRange o = P.own(0, false, rank);
+    sum += (mgk::residual_restrict_partials(n, o) + 2 * mgk::residual_restrict_partials(n, IRange{o.lo, o.lo + 2}) + 1) *
+           (long long)sizeof(double);  // an upper bound of the partial sums of the split residual pass
+    return sum;
+}
+
 extern "C" {
 
 int mg_dist_unique_id(uint8_t out[MG_UNIQUE_ID_BYTES])

@@ -71,6 +71,7 @@ SYMBOLS = {
     "mg_default_config": (C.c_int, [C.POINTER(MgConfig), C.c_int64, C.c_int64, C.c_int64, _f64x3, C.c_int]),
     "mg_default_config_b": (C.c_int, [C.POINTER(MgConfig), C.c_int64, C.c_int64, C.c_int64, _f64x3, C.c_int]),
     "mg_create": (C.c_int, [C.POINTER(MgConfig), C.POINTER(_H)]),
+    "mg_device_bytes": (C.c_int, [C.POINTER(MgConfig), C.POINTER(C.c_uint64)]),
     "mg_destroy": (C.c_int, [_H]),
     "mg_set_rho": (C.c_int, [_H, _dp]),
     "mg_set_phi": (C.c_int, [_H, _dp]),
@@ -187,6 +188,19 @@ def load():
             raise MgError(-101, "ABI version mismatch between libmg_hip.so and libmg.py")
         _lib = lib
     return _lib
+
+
+def device_bytes(n, dh, depth, flags=0, devices=None, coarse_cut=0):
+    """Device memory in bytes a Handle of these arguments allocates (per GPU: the largest share);
+    arithmetic only, no GPU needed."""
+    cfg = default_config(tuple(int(a) for a in n), dh, depth, 0)
+    cfg.flags |= flags
+    if devices is not None and len(devices) > 1:
+        cfg.n_gpus = len(devices)
+        cfg.coarse_cut = coarse_cut
+    out = C.c_uint64(0)
+    _check(load().mg_device_bytes(C.byref(cfg), C.byref(out)))
+    return int(out.value)
 
 
 def _check(rc):

@@ -48,6 +48,22 @@ def test_bad_arguments_are_rejected(mg):
         mg.default_config((41, 41, 41), (1e-2,) * 3, mg.MG_MAX_LEVELS)
 
 
+def test_device_memory_of_a_configuration_is_plain_arithmetic(mg):
+    """mg_device_bytes needs no GPU: the largest BASELINE grid needs 236 GB as a whole (three fine
+    fields of 2049^2 x 2050 doubles each, the coarse levels about a seventh of that) and an eighth
+    of it plus halo planes and the gathered levels per GPU on eight."""
+    dh = (1e-3,) * 3
+    one = mg.device_bytes((2049,) * 3, dh, 7)
+    fine = 3 * 2049 * 2049 * 2050 * 8
+    assert fine < one < fine * 1.16
+    eight = mg.device_bytes((2049,) * 3, dh, 7, devices=list(range(8)))
+    assert one / 8 < eight < one / 8 * 1.05
+    assert mg.device_bytes((41,) * 3, dh, 2, flags=mg.MG_FLAG_RESERVE_EF) - mg.device_bytes((41,) * 3, dh, 2) == 41 ** 3 * 24
+    assert mg.device_bytes((41,) * 3, dh, 2, flags=mg.MG_FLAG_KEEP_FINE_RESIDUAL) > mg.device_bytes((41,) * 3, dh, 2)
+    with pytest.raises(mg.MgError):  # 21 planes cannot be cut into 16 slabs of whole units
+        mg.device_bytes((21,) * 3, dh, 1, devices=list(range(16)))
+
+
 def test_no_silent_cpu_fallback(mg):
     """Without a GPU every compute entry point must fail loudly."""
     if mg.device_count() > 0:

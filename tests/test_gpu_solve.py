@@ -168,3 +168,19 @@ def test_headline_size_first_cycles(gpu, orc):
         got_phi = h.get_phi()
     assert_bit_equal(got_phi, phi, "phi 513^3")
     assert got == pytest.approx(list(hist), rel=1e-12)
+
+
+def test_device_memory_estimate_matches_what_a_handle_allocates(gpu, orc):
+    """mg_device_bytes against the free device memory before and after mg_create (allocations are
+    rounded up to the driver's granularity, so the handle may take a little more, never less)."""
+    import torch
+    N = (257, 257, 257)
+    dh = orc.main_extents_dh(N)
+    want = gpu.device_bytes(N, dh, 5, flags=gpu.MG_FLAG_RESERVE_EF)
+    with gpu.Handle((41, 41, 41), orc.main_extents_dh((41, 41, 41)), 2) as h:  # the runtime's own first-use allocations
+        h.set_phi(np.zeros((41, 41, 41)))
+    torch.cuda.synchronize()
+    before = torch.cuda.mem_get_info(0)[0]
+    with gpu.Handle(N, dh, 5, flags=gpu.MG_FLAG_RESERVE_EF):
+        taken = before - torch.cuda.mem_get_info(0)[0]
+    assert want <= taken <= want * 1.03 + (64 << 20)
