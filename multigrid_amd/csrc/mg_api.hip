@@ -53,9 +53,11 @@ namespace {
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
+        if (e_ != hipSuccess) {                                                              \
+            (void)hipGetLastError(); /* reported here; not left behind for a later call's check */ \
             return fail(e_ == hipErrorOutOfMemory ? MG_ERR_NOMEM : MG_ERR_HIP, "%s: %s (%s:%d)", \
                         #expr, hipGetErrorString(e_), __FILE__, __LINE__);                   \
+        }                                                                                    \
     } while (0)
 
 #define TRY(expr)            \
@@ -517,16 +519,32 @@ int mg_create(const mg_config *cfg, mg_handle **out)
     h->fused_residual = L >= 1 && !(cfg->flags & MG_FLAG_KEEP_FINE_RESIDUAL) && !h->restrict7;
     memset(&h->timers, 0, sizeof(h->timers));
     memset(h->lv, 0, sizeof(h->lv));
-#define CREATE_TRY(expr)          \
-    do {                          \
-        int rc_ = (expr);         \
-        if (rc_) {                \
-            mg_destroy(h);        \
-            return rc_;           \
-        }                         \
+    // out of device memory: say how much this configuration needs in all
+    auto out_of_memory = [&]() -> int {
+        uint64_t need = 0, free_b = 0, total_b = 0;
+        size_t f = 0, t = 0;
+        if (mg_device_bytes(cfg, &need) != MG_OK) return MG_ERR_NOMEM;
+        if (hipMemGetInfo(&f, &t) == hipSuccess) {
+            free_b = f;
+            total_b = t;
+        }
+        return fail(MG_ERR_NOMEM, "out of device memory: this configuration needs %.2f GB on device %d (%.2f of %.2f GB were free "
+                    "when the allocation failed); mg_device_bytes gives the need of a configuration, n_gpus splits the grid over several GPUs",
+                    need / 1e9, cfg->device, free_b / 1e9, total_b / 1e9);
+    };
+#define CREATE_TRY(expr)                              \
+    do {                                              \
+        int rc_ = (expr);                             \
+        if (rc_) {                                    \
+            if (rc_ == MG_ERR_NOMEM) out_of_memory(); \
+            mg_destroy(h);                            \
+            (void)hipGetLastError(); /* reported; not left behind for the next call's check */ \
+            return rc_;                               \
+        }                                             \
     } while (0)
     auto hip_try = [](hipError_t e, const char *what) -> int {
         if (e == hipSuccess) return MG_OK;
+        (void)hipGetLastError();  // reported here; not left behind for a later call's check
         return fail(e == hipErrorOutOfMemory ? MG_ERR_NOMEM : MG_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     };
     CREATE_TRY(hip_try(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate"));

@@ -49,9 +49,11 @@ using mgk::View;
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
+        if (e_ != hipSuccess) {                                                                    \
+            (void)hipGetLastError(); /* reported here; not left behind for a later call's check */ \
             return mgk::set_error(e_ == hipErrorOutOfMemory ? MG_ERR_NOMEM : MG_ERR_HIP, "%s: %s (%s:%d)", #expr, \
                                   hipGetErrorString(e_), __FILE__, __LINE__);                      \
+        }                                                                                          \
     } while (0)
 #define TRY(expr)            \
     do {                     \
@@ -985,6 +987,7 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
     } while (0)
     auto hip_ok = [](hipError_t e, const char *what) -> int {
         if (e == hipSuccess) return MG_OK;
+        (void)hipGetLastError();  // reported here; not left behind for a later call's check
         return mgk::set_error(e == hipErrorOutOfMemory ? MG_ERR_NOMEM : MG_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     };
     d->rank = cfg->rank;

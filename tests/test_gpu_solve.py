@@ -184,3 +184,21 @@ def test_device_memory_estimate_matches_what_a_handle_allocates(gpu, orc):
     with gpu.Handle(N, dh, 5, flags=gpu.MG_FLAG_RESERVE_EF):
         taken = before - torch.cuda.mem_get_info(0)[0]
     assert want <= taken <= want * 1.03 + (64 << 20)
+
+
+def test_out_of_device_memory_says_what_the_configuration_needs(gpu, orc):
+    """2049^3 with seven coarse grids, the fine residual kept and the field's array reserved needs
+    more than one GPU has: mg_create fails with MG_ERR_NOMEM, names the need, and leaves the device
+    usable."""
+    N = (2049, 2049, 2049)
+    dh = orc.main_extents_dh(N)
+    flags = gpu.MG_FLAG_KEEP_FINE_RESIDUAL | gpu.MG_FLAG_RESERVE_EF
+    need = gpu.device_bytes(N, dh, 7, flags=flags)
+    assert need > 500e9
+    with pytest.raises(gpu.MgError) as e:
+        gpu.Handle(N, dh, 7, flags=flags)
+    assert e.value.code == -3 and f"{need / 1e9:.2f} GB" in str(e.value)
+    with gpu.Handle((41, 41, 41), orc.main_extents_dh((41, 41, 41)), 2) as h:  # nothing leaked, nothing sticky
+        h.set_rho(orc.synthetic_rho((41, 41, 41)))
+        h.set_phi(np.zeros((41, 41, 41)))
+        assert np.isfinite(h.vcycles(1))
