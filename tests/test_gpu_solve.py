@@ -202,3 +202,41 @@ def test_out_of_device_memory_says_what_the_configuration_needs(gpu, orc):
         h.set_rho(orc.synthetic_rho((41, 41, 41)))
         h.set_phi(np.zeros((41, 41, 41)))
         assert np.isfinite(h.vcycles(1))
+
+
+def test_handles_give_back_what_they_took(gpu, orc):
+    """Creating, using and destroying handles (single GPU, several slabs on one GPU, one rank driven
+    directly) leaves the free device memory where it was."""
+    import torch
+    from multigrid_amd import problem
+    N = (65, 65, 65)
+    dh = orc.main_extents_dh(N)
+    rho = orc.synthetic_rho(N)
+
+    def one_round():
+        with gpu.Handle(N, dh, 3, flags=gpu.MG_FLAG_RESERVE_EF) as h:
+            h.set_rho(rho)
+            h.set_phi(np.zeros(N))
+            h.vcycles(2)
+            h.compute_ef(download=False)
+        with gpu.Handle(N, dh, 3, devices=[0, 0]) as h:
+            h.set_rho(rho)
+            h.set_phi(np.zeros(N))
+            h.vcycles(2)
+            h.compute_ef(download=False)
+        d = gpu.DistRank(N, dh, 3, 0, 1, device=0)
+        try:
+            d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
+            d.set_phi(lambda lo, hi: np.zeros((hi - lo,) + N[1:]))
+            d.vcycles(1)
+            d.compute_ef_owned()
+        finally:
+            d.close()
+
+    one_round()  # first-use allocations of the runtime
+    torch.cuda.synchronize()
+    before = torch.cuda.mem_get_info(0)[0]
+    for _ in range(10):
+        one_round()
+    torch.cuda.synchronize()
+    assert before - torch.cuda.mem_get_info(0)[0] <= (8 << 20)
