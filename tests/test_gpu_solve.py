@@ -240,3 +240,44 @@ def test_handles_give_back_what_they_took(gpu, orc):
         one_round()
     torch.cuda.synchronize()
     assert before - torch.cuda.mem_get_info(0)[0] <= (8 << 20)
+
+
+@pytest.mark.parametrize("n,depth", [((3, 3, 3), 0), ((5, 4, 3), 0), ((6, 6, 6), 1), ((7, 9, 6), 1), ((12, 12, 12), 2),
+                                      ((13, 12, 14), 2)], ids=str)
+def test_smallest_grids(gpu, orc, n, depth):
+    """Three nodes per axis on the coarsest level is the least the loops allow (one interior node):
+    the Gauss-Seidel solver (depth 0) and the V-cycle still equal the oracle bit for bit."""
+    from util import assert_bit_equal
+    dh = orc.main_extents_dh(n)
+    g = np.random.default_rng(5)
+    rho, phi0 = g.uniform(-1, 1, n) * 8.85e-9, g.uniform(-1, 1, n)
+    want = phi0.copy()
+    with gpu.Handle(n, dh, depth) as h:
+        h.set_rho(rho)
+        h.set_phi(phi0)
+        if depth == 0:
+            got = h.gs_solve(60, 1e-30)
+            ref = orc.gs_solve(want, rho, dh, 60, 1e-30, rb=True)
+            assert got[:2] == tuple(ref[:2]) and got[2] == pytest.approx(ref[2], rel=1e-12)
+        else:
+            l2 = h.vcycles(3)
+            ref = orc.Solver(n, dh, depth).solve(want, rho, 3, 0.0, rb=True)
+            assert l2 == pytest.approx(ref[2], rel=1e-12)
+        assert_bit_equal(h.get_phi(), want, "phi")
+
+
+def test_no_iterations_and_not_a_number(gpu, orc):
+    """max_it = 0 does nothing and reports failure like the reference's loop that never runs
+    (cpp/PotentialSolver.cpp:3756, :4246-4247); a NaN in rho makes every norm NaN, which never passes
+    the tolerance test: the solve runs its max_it cycles and returns false, it does not hang."""
+    N = (41, 41, 41)
+    dh, rho = orc.main_extents_dh(N), orc.synthetic_rho(N)
+    with gpu.Handle(N, dh, 2) as h:
+        h.set_rho(rho)
+        h.set_phi(np.zeros(N))
+        assert h.solve(0, 1e-6) == (False, 0, 0.0)
+        assert not h.get_phi().any()
+        rho[20, 20, 20] = np.nan
+        h.set_rho(rho)
+        ok, cycles, l2 = h.solve(5, 1e-6)
+        assert (ok, cycles) == (False, 5) and np.isnan(l2)
