@@ -193,3 +193,27 @@ def test_a_rank_alone_runs_its_share_of_a_larger_world(gpu):
         h.set_phi(np.zeros(N))
         assert h.vcycles(2) == pytest.approx(l2, rel=1e-12)
         assert_bit_equal(phi, h.get_phi(), "phi of a world of one without transport")
+
+
+@pytest.mark.parametrize("n,depth,world,cut", [((17, 17, 17), 1, 8, 0), ((33, 33, 33), 2, 8, 2), ((21, 9, 11), 1, 5, 0),
+                                               ((65, 20, 24), 2, 4, 1), ((65, 65, 65), 3, 16, 1), ((129, 40, 40), 3, 3, 3)],
+                         ids=str)
+def test_extreme_partitions_equal_the_undivided_handle(gpu, n, depth, world, cut):
+    """Slabs of a single unit of 2^cut planes, sixteen ranks, non-cubic grids, every level
+    distributed: potential and field of the multi-GPU handle (all slabs on GPU 0) equal the
+    single-GPU handle's bit for bit."""
+    from multigrid_amd import problem
+    dh = problem.main_extents_dh(n)
+    g = np.random.default_rng(7)
+    rho, phi0 = g.uniform(-1, 1, n) * 8.85e-9, g.uniform(-1, 1, n)
+    with gpu.Handle(n, dh, depth) as h:
+        h.set_rho(rho)
+        h.set_phi(phi0)
+        l2 = h.vcycles(3)
+        phi, ef = h.get_phi(), h.compute_ef()
+    with gpu.Handle(n, dh, depth, devices=[0] * world, coarse_cut=cut) as h:
+        h.set_rho(rho)
+        h.set_phi(phi0)
+        assert h.vcycles(3) == pytest.approx(l2, rel=1e-12)
+        assert_bit_equal(h.get_phi(), phi, "phi of the slabs")
+        assert_bit_equal(h.compute_ef(), ef, "E of the slabs")
