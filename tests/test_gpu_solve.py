@@ -281,3 +281,39 @@ def test_no_iterations_and_not_a_number(gpu, orc):
         h.set_rho(rho)
         ok, cycles, l2 = h.solve(5, 1e-6)
         assert (ok, cycles) == (False, 5) and np.isnan(l2)
+
+
+def test_handles_on_different_host_threads_do_not_disturb_each_other(gpu, orc):
+    """One handle per host thread is the contract: four threads, each creating, solving with and
+    destroying handles of its own at the same time, get the bits the same solves give one after
+    the other."""
+    import threading
+    from util import assert_bit_equal
+    cases = [((129, 129, 129), 3), ((65, 65, 65), 3), ((100, 90, 80), 2), ((257, 257, 257), 5)]
+
+    def run(n, depth):
+        with gpu.Handle(n, orc.main_extents_dh(n), depth) as h:
+            h.set_rho(orc.synthetic_rho(n))
+            h.set_phi(np.zeros(n))
+            return h.solve(200, 1e-6), h.get_phi(), h.compute_ef()
+
+    alone = {n: run(n, depth) for n, depth in cases}
+    together, errors = {}, []
+
+    def work(n, depth):
+        try:
+            for rep in range(2):
+                together[(n, rep)] = run(n, depth)
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=c) for c in cases]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for (n, rep), (res, phi, ef) in together.items():
+        assert res == alone[n][0]
+        assert_bit_equal(phi, alone[n][1], f"phi of {n}, repetition {rep}")
+        assert_bit_equal(ef, alone[n][2], f"E of {n}, repetition {rep}")
