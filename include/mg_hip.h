@@ -15,7 +15,8 @@
  *     last failure on the calling thread is mg_last_error();
  *   - "flat" host arrays are caller owned, fp64, ((i*nj)+j)*nk+k, k contiguous;
  *   - a handle is bound to one HIP device and is not thread safe (the reference
- *     solver is not re-entrant either: it mutates its members);
+ *     solver is not re-entrant either: it mutates its members); different handles
+ *     may be used from different host threads at the same time;
  *   - the smoother is red-black Gauss-Seidel/SOR, colour (i+j+k)&1 == 0 first,
  *     with the reference's update formula and omega; every other operator
  *     reproduces the reference's arithmetic bit for bit (same association
