@@ -217,3 +217,40 @@ def test_extreme_partitions_equal_the_undivided_handle(gpu, n, depth, world, cut
         assert h.vcycles(3) == pytest.approx(l2, rel=1e-12)
         assert_bit_equal(h.get_phi(), phi, "phi of the slabs")
         assert_bit_equal(h.compute_ef(), ef, "E of the slabs")
+
+
+@pytest.mark.parametrize("devices,cut", [([0, 0], 0), ([0, 0, 0], 2), ([0] * 4, 1)], ids=str)
+def test_sequence_of_warm_started_solves_on_slabs(gpu, devices, cut):
+    """The reference's time loop calls solve() again and again on a changing rho with phi and the
+    coarse corrections left where they were (cpp/Main.cpp:151-166): a solve, a new rho, a solve, an
+    edited phi, a solve -- the slabs take the undivided handle's cycle counts and end on its bits."""
+    from multigrid_amd import problem
+    n, depth = (129, 129, 129), 3
+    dh = problem.main_extents_dh(n)
+    rho1 = problem.synthetic_rho(n)
+    rho2 = rho1 * (1 + 0.05 * np.random.default_rng(3).uniform(-1, 1, n))
+
+    def sequence(h):
+        out = []
+        h.set_rho(rho1)
+        h.set_phi(np.zeros(n))
+        out.append(h.solve(300, 1e-6)[:2])
+        h.set_rho(rho2)
+        out.append(h.solve(300, 1e-6)[:2])
+        phi = h.get_phi()
+        out.append(phi.copy())
+        phi[1:-1, 1:-1, 1:-1] *= 0.5
+        h.set_phi(phi)
+        out.append(h.solve(300, 1e-6)[:2])
+        return out + [h.get_phi(), h.compute_ef()]
+
+    with gpu.Handle(n, dh, depth) as h:
+        want = sequence(h)
+    with gpu.Handle(n, dh, depth, devices=devices, coarse_cut=cut) as h:
+        got = sequence(h)
+    assert want[1][1] < want[0][1]  # the warm start pays
+    for a, b in zip(got, want):
+        if isinstance(b, tuple):
+            assert a == b
+        else:
+            assert_bit_equal(a, b, "field after the sequence")
