@@ -206,3 +206,34 @@ def test_multi_gpu_solver_behind_the_same_interface(box, gpu, tmp_path):
     assert outs[0][2] == outs[1][2]
     assert_bit_equal(outs[1][0], outs[0][0], "phi from three slabs")
     assert_bit_equal(outs[1][1], outs[0][1], "E from the slabs")
+
+
+def _c_example():
+    exe = os.path.join(ROOT, "host", "c_abi_example")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "c_abi_example"], stdout=subprocess.DEVNULL)
+    return exe
+
+
+def test_header_is_plain_c99(mg):
+    """include/mg_hip.h compiled by gcc -std=c99 -pedantic -Wall -Wextra -Werror inside a C program
+    that uses the boundary the way a foreign-function binding does; without a GPU that program
+    stops at mg_create with the library's message."""
+    exe = _c_example()
+    if mg.device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = subprocess.run([exe, "21", "1"], capture_output=True, text=True)
+    assert p.returncode == 1 and "no HIP device" in p.stderr
+    assert "MB of device memory" in p.stdout  # mg_device_bytes needs no device
+
+
+@pytest.mark.gpu
+def test_solve_from_plain_c(gpu, orc, tmp_path):
+    n, depth = 41, 2
+    out = tmp_path / "phi.bin"
+    p = subprocess.run([_c_example(), str(n), str(depth), "1e-6", str(out)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    N = (n, n, n)
+    want = np.zeros(N)
+    ok, cycles, _, _ = orc.Solver(N, orc.main_extents_dh(N), depth).solve(want, orc.synthetic_rho(N), 10000, 1e-6, rb=True)
+    assert ok and f"converged=1 cycles={cycles} " in p.stdout
+    assert rel_l2(np.fromfile(out).reshape(N), want) <= 1e-9  # rho comes from the C library's sin(): last-bit differences
