@@ -74,3 +74,37 @@ def test_prolongation_and_correction_on_random_shapes(gpu, orc, shape):
     orc.prolong(ec, eps_h, shape)
     want = orc.correct(phi.copy(), eps_h)
     assert_bit_equal(gpu.op_prolong_correct(ec, phi.copy()), want, "prolongation + correction")
+
+
+def _cycle_cases():
+    g = np.random.default_rng(int(os.environ.get("MG_FUZZ_SEED", "20261111")) + 1)
+    out = []
+    for _ in range(8 * int(os.environ.get("MG_FUZZ_MULT", "1"))):
+        hi = int(g.choice([40, 90, 160, 280]))
+        n = tuple(int(x) for x in g.integers(12, hi, size=3))
+        deepest = 0
+        while (min(n) >> (deepest + 1)) >= 3:
+            deepest += 1
+        out.append((n, int(g.integers(1, min(deepest, 6) + 1)), ("plain", "keep_fine_residual", "b_variant")[int(g.choice([0, 0, 1, 2]))],
+                    int(g.integers(1, 4))))
+    return out
+
+
+@pytest.mark.parametrize("n,depth,mode,cycles", _cycle_cases(), ids=str)
+def test_whole_cycles_on_random_shapes(gpu, orc, n, depth, mode, cycles):
+    """The whole V-cycle (every level's kernel choice follows from the shape) on non-cubic grids of
+    random size and depth, in the default form, with the fine residual kept, and as the "B" variant:
+    phi after a few iterations equals the oracle's red-black twin bit for bit."""
+    g = rng(13 + sum(n))
+    dh = dh_for(n)
+    rho, phi0 = g.uniform(-1, 1, n) * 8.85e-9, g.uniform(-1, 1, n)
+    flags = gpu.MG_FLAG_KEEP_FINE_RESIDUAL if mode == "keep_fine_residual" else 0
+    with gpu.Handle(n, dh, depth, flags=flags, variant_b=mode == "b_variant") as h:
+        h.set_rho(rho)
+        h.set_phi(phi0)
+        l2 = h.vcycles(cycles)
+        phi = h.get_phi()
+    want = phi0.copy()
+    ref = orc.Solver(n, dh, depth, variant_b=mode == "b_variant").solve(want, rho, cycles, 0.0, rb=True)
+    assert l2 == pytest.approx(ref[2], rel=1e-11)
+    assert_bit_equal(phi, want, "phi")
