@@ -254,3 +254,49 @@ def test_sequence_of_warm_started_solves_on_slabs(gpu, devices, cut):
             assert a == b
         else:
             assert_bit_equal(a, b, "field after the sequence")
+
+
+def _partition_cases():
+    import os
+    g = np.random.default_rng(int(os.environ.get("MG_FUZZ_SEED", "20261111")) + 2)
+    out = []
+    for _ in range(6 * int(os.environ.get("MG_FUZZ_MULT", "1"))):
+        n = tuple(int(x) for x in g.integers(20, int(g.choice([60, 140, 270])), size=3))
+        deepest = 0
+        while (min(n) >> (deepest + 1)) >= 3:
+            deepest += 1
+        depth = int(g.integers(1, min(deepest, 5) + 1))
+        out.append((n, depth, int(g.integers(2, 9)), int(g.integers(0, depth + 1)), bool(g.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("n,depth,world,cut,solve", _partition_cases(), ids=str)
+def test_random_partitions_equal_the_undivided_handle(gpu, n, depth, world, cut, solve):
+    """Random non-cubic grids cut into a random number of slabs at a random level (cut 0 = the
+    library's choice): cycles or a solve on the slabs end on the undivided handle's bits.  A grid that
+    cannot be cut that way must be refused by mg_create, not mis-solved."""
+    from multigrid_amd import problem
+    dh = problem.main_extents_dh(n)
+    g = np.random.default_rng(17 + sum(n))
+    rho, phi0 = g.uniform(-1, 1, n) * 8.85e-9, g.uniform(-1, 1, n)
+
+    def run(h):
+        h.set_rho(rho)
+        h.set_phi(phi0)
+        head = h.solve(40, 1e-3)[:2] if solve else None
+        if not solve:
+            h.vcycles(2)
+        return head, h.get_phi(), h.compute_ef()
+
+    try:
+        h = gpu.Handle(n, dh, depth, devices=[0] * world, coarse_cut=cut)
+    except gpu.MgError as e:
+        assert e.code == -1 and "planes over" in str(e)  # too few planes for that many slabs of 2^cut
+        return
+    with h:
+        got = run(h)
+    with gpu.Handle(n, dh, depth) as h:
+        want = run(h)
+    assert got[0] == want[0]
+    assert_bit_equal(got[1], want[1], "phi of the slabs")
+    assert_bit_equal(got[2], want[2], "E of the slabs")
