@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def run_ranks(gpu, world, n, depth, cut, body, hold_back=False, overlap=True):
     """body(rank_object, rank) on `world` threads; returns their results by rank."""
     from multigrid_amd import problem
-    N = (n, n, n)
+    N = (n, n, n) if isinstance(n, int) else tuple(n)
     dh = problem.main_extents_dh(N)
     group = gpu.LocalGroup(world, hold_back) if world > 1 else None
     out, err = [None] * world, [None] * world
@@ -27,7 +27,7 @@ def run_ranks(gpu, world, n, depth, cut, body, hold_back=False, overlap=True):
         try:
             d = gpu.DistRank(N, dh, depth, r, world, device=0, local_group=group, coarse_cut=cut, overlap=overlap)
             d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
-            d.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
+            d.set_phi(lambda lo, hi: np.zeros((hi - lo,) + N[1:]))
             out[r] = body(d, r)
         except BaseException as e:  # noqa: BLE001 -- reported by the main thread
             err[r] = e
@@ -300,3 +300,36 @@ def test_random_partitions_equal_the_undivided_handle(gpu, n, depth, world, cut,
     assert got[0] == want[0]
     assert_bit_equal(got[1], want[1], "phi of the slabs")
     assert_bit_equal(got[2], want[2], "E of the slabs")
+
+
+def _late_exchange_cases():
+    import os
+    g = np.random.default_rng(int(os.environ.get("MG_FUZZ_SEED", "20261111")) + 3)
+    out = []
+    for _ in range(4 * int(os.environ.get("MG_FUZZ_MULT", "1"))):
+        n = (int(g.integers(40, 200)), int(g.integers(130, 280)), int(g.integers(130, 280)))
+        depth = int(g.integers(1, 4))
+        out.append((n, depth, int(g.integers(2, 5)), int(g.integers(1, depth + 1))))
+    return out
+
+
+@pytest.mark.parametrize("n,depth,world,cut", _late_exchange_cases(), ids=str)
+def test_overlapped_schedule_with_every_exchange_held_back_on_random_grids(gpu, n, depth, world, cut):
+    """Grids wide enough for the out-of-place sweep (the edge / exchange / interior schedule and the
+    split residual pass) cut at random, every halo exchange completed only when its planes are next
+    read: a wait missing from the schedule would show as wrong bits against the undivided handle."""
+    from multigrid_amd import problem
+    try:
+        res = run_ranks(gpu, world, n, depth, cut, lambda d, r: (d.vcycles(2),) + d.get_phi_owned(), hold_back=True)
+    except gpu.MgError as e:
+        assert e.code == -1 and "planes over" in str(e)
+        return
+    got = np.full(n, np.nan)
+    for _, lo, part in res:
+        got[lo:lo + part.shape[0]] = part
+    with gpu.Handle(n, problem.main_extents_dh(n), depth) as h:
+        h.set_rho(problem.synthetic_rho(n))
+        h.set_phi(np.zeros(n))
+        l2 = h.vcycles(2)
+        assert_bit_equal(got, h.get_phi(), "phi assembled from the slabs")
+    assert all(r[0] == pytest.approx(l2, rel=1e-12) for r in res)
