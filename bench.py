@@ -582,6 +582,13 @@ def s_cut(N, depth, world):
     return SlabPlan(N, depth, world).cut
 
 
+def visible_gpus():
+    """GPUs this process could use, counted without initialising the HIP runtime (this process goes
+    on to start the ranks as child programs and must not have touched a GPU itself)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
 def spawn_ranks(n_gpus):
     """`python bench.py --gpus N` typed as is: this process has made no GPU call yet and makes none;
     it starts one rank per GPU under torch.distributed.run with the same arguments, relays rank 0's
@@ -619,6 +626,10 @@ def main():
         if os.environ.get("MG_BENCH_SHARE_GPU") and os.environ.get("MG_BENCH_DRIVER") != "python":
             run_shared_gpu_rehearsal(args)
             return
+        have = visible_gpus()
+        if args.gpus > have:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} asks for more GPUs than this machine shows ({have}); "
+                             f"nothing was started (MG_BENCH_SHARE_GPU=1 rehearses the partitioned path on one GPU)")
         raise SystemExit(spawn_ranks(args.gpus))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}")

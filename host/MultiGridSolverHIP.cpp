@@ -29,25 +29,34 @@ bool rows_contiguous(F &f)
     return true;
 }
 
-// Node p of the sample that stands for "world.phi is what the device holds": 4096 nodes spread by
-// a multiplicative hash, then the six face centres and the eight corners.
-constexpr int kScattered = 4096, kSample = kScattered + 14;
+// Node p of the interior sample of the "world.phi is what the device holds" test: 4096 nodes spread
+// by a multiplicative hash.
+constexpr int kScattered = 4096;
 void sample_node(const Field &f, int p, int &i, int &j, int &k)
 {
-    if (p < kScattered) {
-        const std::uint64_t total = std::uint64_t(f.ni) * f.nj * f.nk;
-        const std::uint64_t q = (std::uint64_t(p) * 0x9E3779B97F4A7C15ull >> 11) % total;
-        k = int(q % f.nk);
-        j = int(q / f.nk % f.nj);
-        i = int(q / f.nk / f.nj);
-        return;
+    const std::uint64_t total = std::uint64_t(f.ni) * f.nj * f.nk;
+    const std::uint64_t q = (std::uint64_t(p) * 0x9E3779B97F4A7C15ull >> 11) % total;
+    k = int(q % f.nk);
+    j = int(q / f.nk % f.nj);
+    i = int(q / f.nk / f.nj);
+}
+
+// Calls fn(value) for every node of the six faces of f, in a fixed order (edge and corner nodes
+// more than once).  The Dirichlet values of the solve live on these nodes (cpp/World.cpp:40-52).
+template <typename F, typename Fn>
+void for_each_face_node(F &f, Fn fn)
+{
+    for (int i = 0; i < f.ni; i += (f.ni > 1 ? f.ni - 1 : 1))
+        for (int j = 0; j < f.nj; j++)
+            for (int k = 0; k < f.nk; k++) fn(f[i][j][k]);
+    for (int i = 0; i < f.ni; i++) {
+        for (int j = 0; j < f.nj; j += (f.nj > 1 ? f.nj - 1 : 1))
+            for (int k = 0; k < f.nk; k++) fn(f[i][j][k]);
+        for (int j = 0; j < f.nj; j++) {
+            fn(f[i][j][0]);
+            fn(f[i][j][f.nk - 1]);
+        }
     }
-    p -= kScattered;
-    const int hi[3] = {f.ni - 1, f.nj - 1, f.nk - 1};
-    int c[3] = {hi[0] / 2, hi[1] / 2, hi[2] / 2};
-    if (p < 6) c[p / 2] = (p & 1) ? hi[p / 2] : 0;                                 // face centres
-    else for (int a = 0; a < 3; a++) c[a] = ((p - 6) >> a & 1) ? hi[a] : 0;        // corners
-    i = c[0]; j = c[1]; k = c[2];
 }
 
 }  // namespace
@@ -124,27 +133,41 @@ MultiGridSolverHIP::~MultiGridSolverHIP()
     if (stage) mg_host_free(stage);
 }
 
+// Only with setAssumePhiUntouched(true): every face node (the Dirichlet values: a stale one would
+// change the converged answer) and a scattered sample of the interior (a stale initial guess only
+// costs iterations) must still hold what the last solve() returned.
 bool MultiGridSolverHIP::device_phi_current()
 {
-    if (!device_phi_valid || phi_sample.size() != std::size_t(kSample)) return false;
+    if (!assume_untouched || !device_phi_valid || phi_sample.size() != std::size_t(kScattered)) return false;
     Field &phi = world.phi;
-    for (int p = 0; p < kSample; p++) {
+    for (int p = 0; p < kScattered; p++) {
         int i, j, k;
         sample_node(phi, p, i, j, k);
         if (std::memcmp(&phi[i][j][k], &phi_sample[p], sizeof(double)) != 0) return false;
     }
-    return true;
+    std::size_t at = 0;
+    bool same = true;
+    const std::vector<double> &kept = phi_faces;
+    for_each_face_node(phi, [&](const double &v) {
+        if (at >= kept.size() || std::memcmp(&v, &kept[at], sizeof(double)) != 0) same = false;
+        at++;
+    });
+    return same && at == kept.size();
 }
 
 void MultiGridSolverHIP::remember_phi()
 {
+    device_phi_valid = false;
+    if (!assume_untouched) return;  // the next call uploads whatever world.phi holds then
     Field &phi = world.phi;
-    phi_sample.resize(kSample);
-    for (int p = 0; p < kSample; p++) {
+    phi_sample.resize(kScattered);
+    for (int p = 0; p < kScattered; p++) {
         int i, j, k;
         sample_node(phi, p, i, j, k);
         phi_sample[p] = phi[i][j][k];
     }
+    phi_faces.clear();
+    for_each_face_node(phi, [&](const double &v) { phi_faces.push_back(v); });
     device_phi_valid = true;
 }
 

@@ -19,13 +19,17 @@
 // driver has no handler, so the program stops with that message); setErrorPolicy(ReturnFalse)
 // makes solve() print the message to stderr and return false instead.
 //
-// Host <-> device traffic of a solve(): rho up, phi down.  The potential is uploaded only when
-// the device copy may be stale: on the first call, after invalidate(), or when a sample of
-// world.phi (4096 scattered nodes plus face centres and corners) no longer matches what the last
-// solve() returned -- in the reference's time loop phi is not written between solves
-// (cpp/Main.cpp:151-166).  Code that edits a few nodes of world.phi between solves must call
-// invalidate().  Fields whose rows are contiguous are page-locked in place for the solver's
-// lifetime, so the copies run at the full host-link rate.
+// Host <-> device traffic of a solve(): rho and phi up, phi down -- solve() and computeEF() read the
+// CURRENT world.phi in full on every call, as the reference does (its Fields live in host memory):
+// an electrode patch written onto a face, or any other edit between two solves, is always seen.
+// A driver that never writes world.phi between solves (the reference's time loop does not,
+// cpp/Main.cpp:151-166) can save the upload with setAssumePhiUntouched(true): the potential is then
+// uploaded only on the first call, after invalidate(), or when world.phi no longer matches what the
+// last solve() returned on ALL nodes of the six faces (where the Dirichlet values live,
+// cpp/World.cpp:40-52) and on 4096 scattered interior nodes; an edit of a few interior nodes alone
+// (which can only cost iterations, never change the converged answer) must be announced with
+// invalidate() in that mode.  Fields whose rows are contiguous are page-locked in place for the
+// solver's lifetime, so the copies run at the full host-link rate.
 //
 // This header and MultiGridSolverHIP.cpp use only the public surface of World and Field
 // (phi, rho, ef, getDh(), ni/nj/nk, f[i][j] row pointers), so they also compile against the
@@ -74,6 +78,10 @@ public:
 
     enum ErrorPolicy { Throw, ReturnFalse };
     void setErrorPolicy(ErrorPolicy p) { on_error = p; }
+    // on: the caller promises not to write world.phi between this solver's calls except through
+    // invalidate(); the upload of phi is then skipped while the faces and a sample of the interior
+    // still hold the last result.  Off (the default): every call uploads world.phi.
+    void setAssumePhiUntouched(bool on) { assume_untouched = on; if (!on) device_phi_valid = false; }
     // world.phi was edited by someone else: upload it again at the next solve() / computeEF()
     void invalidate() { device_phi_valid = false; }
 
@@ -104,6 +112,8 @@ private:
     std::size_t stage_doubles = 0;
     std::vector<void *> registered;  // host blocks this solver page-locked in place
     std::vector<double> phi_sample;  // world.phi at the sample nodes when the device copy was last in step
+    std::vector<double> phi_faces;   // and on every node of the six faces
+    bool assume_untouched = false;
     bool device_phi_valid = false;
     unsigned phi_uploads = 0;
     ErrorPolicy on_error = Throw;

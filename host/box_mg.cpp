@@ -13,8 +13,13 @@
 //   --vti file writes phi, rho and ef as VTK ImageData in the reference's ASCII format
 //   --gpus 0,1,2,3 splits the grid into slabs over those GPUs (an ordinal may repeat);
 //   --pageable keeps the World's fields in ordinary memory (default: page-locked blocks);
-//   --again repeats solve() twice more: once with world.phi untouched (the device copy is reused),
-//   once after the driver has reset world.phi to zero (noticed, uploaded again);
+//   --again repeats solve() twice more: once with world.phi untouched, once after the driver has
+//   reset world.phi to zero; --assume-untouched lets the solver skip the upload of a world.phi
+//   that still holds its last result (setAssumePhiUntouched: the first repeat then uploads nothing,
+//   the second is noticed and uploaded);
+//   --edit face|interior writes 5 V into one node of world.phi after the first solve -- an
+//   off-centre node of the j = 0 wall (an electrode patch) or an interior node -- and solves again;
+//   --invalidate announces that edit with invalidate(); --max-it N bounds every solve;
 //   depth 0 selects the plain Gauss-Seidel/SOR solver; --dump writes phi as raw fp64 [i][j][k],
 //   --dump-ef the electric field as raw fp64 [i][j][k][3]
 #include <chrono>
@@ -47,7 +52,9 @@ int main(int argc, char **argv)
     int n = 41, depth = 2;
     double tol = 1e-4;
     const char *dump = nullptr, *dump_ef = nullptr, *vti = nullptr;
-    bool variant_b = false, again = false, pageable = false, menu = false;
+    bool variant_b = false, again = false, pageable = false, menu = false, assume_untouched = false, invalidate = false;
+    const char *edit = nullptr;
+    int max_it = 0;
     std::vector<int> gpus;
     int pos = 0;
     for (int a = 1; a < argc; a++) {
@@ -56,6 +63,10 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--b")) variant_b = true;
         else if (!strcmp(argv[a], "--again")) again = true;
         else if (!strcmp(argv[a], "--menu")) menu = true;
+        else if (!strcmp(argv[a], "--assume-untouched")) assume_untouched = true;
+        else if (!strcmp(argv[a], "--invalidate")) invalidate = true;
+        else if (!strcmp(argv[a], "--edit") && a + 1 < argc) edit = argv[++a];
+        else if (!strcmp(argv[a], "--max-it") && a + 1 < argc) max_it = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--pageable")) pageable = true;
         else if (!strcmp(argv[a], "--gpus") && a + 1 < argc) {
             for (char *t = strtok(argv[++a], ","); t; t = strtok(nullptr, ",")) gpus.push_back(atoi(t));
@@ -64,6 +75,14 @@ int main(int argc, char **argv)
         else if (pos == 0) { n = atoi(argv[a]); pos++; }
         else if (pos == 1) { depth = atoi(argv[a]); pos++; }
         else if (pos == 2) { tol = atof(argv[a]); pos++; }
+    }
+    if (variant_b && gpus.size() > 1) {
+        std::cerr << "box_mg: --b (7-point restriction) is not available together with --gpus" << std::endl;
+        return 1;
+    }
+    if (edit && strcmp(edit, "face") && strcmp(edit, "interior")) {
+        std::cerr << "box_mg: --edit takes face or interior" << std::endl;
+        return 1;
     }
     std::cout << "Using mesh size : " << n << "x" << n << "x" << n << std::endl;
     if (menu) {
@@ -106,9 +125,11 @@ int main(int argc, char **argv)
                                          (std::sin(pi * x) * std::sin(pi * y) * std::sin(pi * z) +
                                           0.5 * std::sin(5 * pi * x) * std::sin(3 * pi * y) * std::sin(7 * pi * z));
                 }
-        MultiGridSolverHIP *mg = depth == 0       ? new GaussSeidelSolverHIP(world, menu ? 10000 : 100000, tol)
-                                 : gpus.size() > 1 ? new MultiGridSolverHIP(world, 10000, tol, depth, gpus)
-                                                   : new MultiGridSolverHIP(world, 10000, tol, depth, 0, variant_b);
+        const int its = max_it > 0 ? max_it : (depth == 0 && !menu ? 100000 : 10000);
+        MultiGridSolverHIP *mg = depth == 0       ? new GaussSeidelSolverHIP(world, its, tol)
+                                 : gpus.size() > 1 ? new MultiGridSolverHIP(world, its, tol, depth, gpus)
+                                                   : new MultiGridSolverHIP(world, its, tol, depth, 0, variant_b);
+        mg->setAssumePhiUntouched(assume_untouched);
         PotentialSolver *solver = mg;  // used through the base pointer, like the reference driver
         auto t0 = std::chrono::high_resolution_clock::now();
         const bool ok = solver->solve();
@@ -119,8 +140,18 @@ int main(int argc, char **argv)
         (void)pageable;
         std::cout << "converged=" << ok << " cycles=" << mg->cycles() << " L2=" << mg->residualNorm()
                   << " device_ms=" << mg->deviceMilliseconds() << std::endl;
+        if (edit) {
+            // a Dirichlet value written onto a wall away from its centre, or one interior node
+            if (!strcmp(edit, "face")) world.phi[n / 3][0][n / 4 + 1] = 5.0;
+            else world.phi[n / 3][n / 2 + 1][n / 4 + 1] = 5.0;
+            if (invalidate) mg->invalidate();
+            const bool ok2 = solver->solve();
+            solver->computeEF();
+            std::cout << "edit: converged=" << ok2 << " cycles=" << mg->cycles() << " phi_uploads=" << mg->phiUploads()
+                      << " L2=" << mg->residualNorm() << std::endl;
+        }
         if (again) {
-            const bool ok2 = solver->solve();  // phi untouched: no upload, stops at its first test
+            const bool ok2 = solver->solve();  // phi untouched: stops at its first test
             std::cout << "again: converged=" << ok2 << " cycles=" << mg->cycles() << " phi_uploads=" << mg->phiUploads()
                       << std::endl;
             world.phi.clear();                 // a new initial guess: must be noticed and uploaded
@@ -153,7 +184,7 @@ int main(int argc, char **argv)
         }
         if (vti && !Output::fields(world, vti)) return 3;
         delete solver;
-        return ok ? 0 : 2;
+        return ok || edit ? 0 : 2;
     } catch (const std::exception &e) {
         std::cerr << "box_mg: " << e.what() << std::endl;
         return 1;

@@ -14,7 +14,7 @@ from util import assert_bit_equal
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(gpu, world, n, depth, cut, body, hold_back=False, overlap=True):
+def run_ranks(gpu, world, n, depth, cut, body, hold_back=False, overlap=True, join_timeout=240):
     """body(rank_object, rank) on `world` threads; returns their results by rank."""
     from multigrid_amd import problem
     N = (n, n, n) if isinstance(n, int) else tuple(n)
@@ -39,7 +39,7 @@ def run_ranks(gpu, world, n, depth, cut, body, hold_back=False, overlap=True):
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=240)
+        t.join(timeout=join_timeout)
     assert not any(t.is_alive() for t in threads), "a rank is stuck"
     for e in err:
         if e is not None:

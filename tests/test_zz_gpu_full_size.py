@@ -1,15 +1,18 @@
-"""Full-size property check at the multi-GPU configuration's grid, 1025^3 (six coarse grids): the
-potential after two V-cycles must not depend on how the grid is partitioned.  Two ranks (sharing
-the test box's one GPU, halo planes over gloo) run the slab-partitioned driver; one undivided
-handle runs the same two cycles; per-plane checksums of the two results must be equal bit for
-bit.  The CPU oracle is not involved (a 1025^3 cycle takes it minutes): what ties this size to
-the oracle is the bit-exact agreement of the same kernels with it at 513^3 and below."""
-import json
+"""Full-size property checks at the multi-GPU configuration's grid, 1025^3 (six coarse grids): the
+potential after two V-cycles must not depend on how the grid is partitioned.  The library's own
+slab driver (mg_dist: the code `bench.py --gpus N` and MultiGridSolverHIP(..., devices) run) is
+started with 8, 4 and 2 ranks -- host threads sharing the test box's one GPU, halo planes by
+device-to-device copies, every exchange completed as early or as late as the schedule allows --
+with the plan it would use on that many GPUs; one undivided handle runs the same two cycles;
+per-plane checksums of the bit patterns must be equal.  The CPU oracle is not involved (a 1025^3
+cycle takes it minutes): what ties this size to the oracle is the bit-exact agreement of the same
+kernels with it at 513^3 and below."""
 import os
-import socket
 
 import numpy as np
 import pytest
+
+from test_gpu_dist_native import run_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -18,59 +21,46 @@ DEPTH = 6
 CYCLES = 2
 
 
-def free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def plane_checksums(a):
     """Two 64-bit checksums per plane of a float64 array, over the bit patterns."""
     u = np.ascontiguousarray(a).view(np.uint64).reshape(a.shape[0], -1)
     return [[int(x), int(s)] for x, s in zip(np.bitwise_xor.reduce(u, axis=1), u.sum(axis=1, dtype=np.uint64))]
 
 
-def _worker(rank, world, port, out_dir):
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from multigrid_amd import dist as mgd, problem
-        N = (N1,) * 3
-        s = mgd.DistSolver(N, problem.main_extents_dh(N), DEPTH, mgd.HipOps(0), mgd.Comm())
-        s.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
-        s.set_phi(lambda lo, hi: np.zeros((hi - lo, N1, N1)))
-        hist = []
-        for _ in range(CYCLES):
-            s.smooth_and_residual()
-            hist.append(s.l2())
-            s.coarse_correction()
-        lo, phi = s.get_phi_owned()
-        with open(os.path.join(out_dir, f"sums_{rank}.json"), "w") as f:
-            json.dump({"lo": lo, "sums": plane_checksums(phi), "hist": hist}, f)
-    finally:
-        dist.destroy_process_group()
-
-
-def test_two_slabs_equal_the_undivided_grid_at_1025(gpu, tmp_path):
-    import torch.multiprocessing as mp
+@pytest.fixture(scope="module")
+def undivided_1025(gpu):
+    """Per-plane checksums and norm history of two cycles on the whole 1025^3 grid (one handle)."""
     from multigrid_amd import problem
-    world = 2
-    mp.spawn(_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
     N = (N1,) * 3
     with gpu.Handle(N, problem.main_extents_dh(N), DEPTH) as h:
         h.set_rho(problem.synthetic_rho(N))
         h.set_phi(np.zeros(N))
         hist = [h.vcycles(1) for _ in range(CYCLES)]
-        want = plane_checksums(h.get_phi())
+        sums = plane_checksums(h.get_phi())
+    return sums, hist
+
+
+@pytest.mark.parametrize("world,hold_back", [(8, True), (8, False), (4, True), (2, True)],
+                         ids=["8_ranks_exchange_late", "8_ranks_exchange_early", "4_ranks_exchange_late",
+                              "2_ranks_exchange_late"])
+def test_slab_plans_of_the_scaling_run_equal_the_undivided_grid_at_1025(gpu, undivided_1025, world, hold_back):
+    want, hist = undivided_1025
+
+    def body(d, r):
+        h = [d.vcycles(1) for _ in range(CYCLES)]
+        lo, phi = d.get_phi_owned()
+        return lo, d.own, d.cut, plane_checksums(phi), h
+
+    res = run_ranks(gpu, world, N1, DEPTH, 0, body, hold_back, join_timeout=900)
     got = [None] * N1
-    for r in range(world):
-        part = json.load(open(tmp_path / f"sums_{r}.json"))
-        for i, s in enumerate(part["sums"]):
-            got[part["lo"] + i] = s
-        if r == 0:
-            assert part["hist"] == pytest.approx(hist, rel=1e-12)
+    for lo, own, cut, sums, h in res:
+        assert cut == 3 and own[0] == lo and own[1] - own[0] == len(sums)
+        for i, s in enumerate(sums):
+            got[lo + i] = s
+        assert h == pytest.approx(hist, rel=1e-12) and h == res[0][4]
+    # the plan of the strong-scaling run: whole units of 2^cut planes, rank 0 relieved of some
+    sizes = [own[1] - own[0] for _, own, _, _, _ in res]
+    assert sum(sizes) == N1 and all(s % 8 == 0 for s in sizes[:-1]) and sizes[0] <= sizes[1]
     assert all(g is not None for g in got)
     bad = [i for i in range(N1) if got[i] != want[i]]
     assert not bad, f"planes that differ between the partitioned and the undivided solve: {bad[:8]} ..."
