@@ -325,7 +325,12 @@ int mg_dev_residual_restrict(void *stream, const mg_dev_array *phi, const mg_dev
  * counterpart in the reference.  The per-workgroup partial sums go to a workspace built into the
  * library (a 1 MiB array in each device's global memory, held until the process ends) and
  * sumsq[0] (device memory, or mapped host memory) receives their sum in the same fixed order, so
- * Rc and the sum are bit-identical to the two-call form.  The call allocates and frees nothing.
+ * Rc and the sum are bit-identical to the two-call form.  The call allocates and frees nothing,
+ * with one exception: the FIRST call on a device looks the workspace's address up, and if no kernel
+ * of this library has run on that device before, the runtime loads the library's code there at
+ * that moment (which allocates its global data, this workspace included, and cannot be captured).
+ * Make one warm-up call per device, outside any capture, before relying on this.  The workspace
+ * used is that of the device `stream` belongs to (of the current device for the null stream).
  * A plane range whose launch has more than 131072 workgroups is rejected with MG_ERR_INVALID
  * (2049 x 2049 planes in chunks of up to 64 stay below that).  All calls on one device share the
  * workspace: calls that overlap in time on one device (different streams or threads) race. */
@@ -368,7 +373,11 @@ int mg_dev_compute_ef(void *stream, const mg_dev_array *phi, void *ef, int64_t e
 /* ---- slab-partitioned solve, one rank per GPU --------------------------------
  * The cycle of mg_solve on a grid whose i-planes are divided among `world` ranks, each bound to
  * one GPU and driven by one host thread or process.  No counterpart in the reference (one CPU
- * thread, cpp/PotentialSolver.cpp:3756-4216); results are bit-identical to the undivided handle.
+ * thread, cpp/PotentialSolver.cpp:3756-4216).  phi (and E) after any number of cycles is bit-identical
+ * to the undivided handle's.  The residual norm is not: each rank sums the squares of its slab and
+ * the sums are all-reduced, which associates the additions differently from the one-GPU sum, so
+ * L2 agrees to rounding (~1e-15 relative) and a solve whose norm passes within that distance of
+ * tol may stop one cycle earlier or later than the undivided handle.
  * Every rank of a group makes the same sequence of mg_dist_* calls (create, vcycles / solve,
  * destroy are collective).  Halo planes travel by RCCL send/recv (MG_TRANSPORT_RCCL: rank 0 makes
  * a unique id with mg_dist_unique_id, the caller hands the same 128 bytes to every rank -- over
@@ -419,6 +428,12 @@ int mg_dist_solve(mg_dist *d, unsigned max_it, double tol, int *converged, unsig
 int mg_dist_compute_ef(mg_dist *d);
 int mg_dist_get_ef_planes(mg_dist *d, int64_t lo, int64_t hi, double *dense);
 int mg_dist_sync(mg_dist *d);
+/* Gives up this rank's communication (ncclCommAbort; the in-process group is released): pending
+ * transfers end, host calls blocked on them return, and every later collective call on the rank
+ * returns MG_ERR_COMM.  May be called from any thread, also while the rank's own thread is inside
+ * a call -- it is how a supervisor releases the ranks of a group one of which has failed.  A rank
+ * whose own collective call fails does this to itself.  Only mg_dist_destroy is useful afterwards. */
+int mg_dist_abort(mg_dist *d);
 /* Device time of the last vcycles/solve call and bytes this rank has sent so far. */
 int mg_dist_stats(mg_dist *d, double *last_ms, uint64_t *bytes_sent);
 

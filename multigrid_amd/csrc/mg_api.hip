@@ -9,7 +9,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -119,10 +121,38 @@ struct Level {
 }  // namespace
 
 // A handle created with n_gpus > 1: one slab-partitioned rank per GPU, each driven by a host
-// thread of its own for the duration of a call.
+// thread of its own that lives as long as the handle (the calls are collective: every rank must be
+// inside the call for any of them to finish).
 struct MultiGpu {
     std::vector<mg_dist *> ranks;
     mg_local_group *group = nullptr;  // in-process transport (an ordinal repeats in devices[])
+
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::function<int(int)> job;
+    uint64_t job_id = 0;
+    int pending = 0;
+    bool quit = false;
+    std::vector<int> rc;
+    std::vector<std::string> err;
+
+    // Starts one worker per rank; false when the threads cannot be created.
+    bool start(int n);
+    // Runs f(rank) on every worker and waits for all of them.
+    void run(const std::function<int(int)> &f);
+    void stop();
+    // A rank's call failed: release the others (they may be waiting for its planes).
+    void give_up()
+    {
+        std::vector<mg_dist *> all;
+        {
+            std::lock_guard<std::mutex> lock(m);
+            all = ranks;
+        }
+        for (mg_dist *d : all)
+            if (d) mg_dist_abort(d);
+    }
 };
 
 struct mg_handle {
@@ -273,8 +303,9 @@ void enqueue_coarse_correction(mg_handle *h)
         if (l < L) {
             // prolongation of eps_{l+1} as the initial guess, then nu_l sweeps
             Prof p(h, MG_T_SMOOTH_COARSE, (32.0 * v.nu + 9.0) * Nl);
+            // eps_l is zero outside 0..n_l-2 (nothing ever writes there), so the fused form need not read it
             p.launches = mgk::prolong_smooth_rb(h->stream, h->lv[l + 1].eps, false, &v.eps, &v.eps_alt, v.R, v.n,
-                                                v.c, h->cfg.omega, v.nu, all);
+                                                v.c, h->cfg.omega, v.nu, all, IRange{0, 0}, true);
         } else {
             Prof p(h, MG_T_SMOOTH_COARSE, 32.0 * Nl * v.nu);
             p.launches = mgk::smooth_rb(h->stream, &v.eps, &v.eps_alt, v.R, v.n, v.c, h->cfg.omega, v.nu, all);
@@ -289,23 +320,73 @@ double l2_from_sum(const mg_handle *h, double sum)
     return std::sqrt(sum / (double)count3(h->lv[0].n));
 }
 
-// Runs f(rank) for every rank of a multi-GPU handle, each on a host thread of its own (the calls
-// are collective: every rank must be inside the call for any of them to finish).
+}  // namespace
+
+bool MultiGpu::start(int n)
+{
+    rc.assign(n, 0);
+    err.assign(n, std::string());
+    try {
+        for (int r = 0; r < n; r++)
+            workers.emplace_back([this, r] {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::function<int(int)> mine;
+                    {
+                        std::unique_lock<std::mutex> lock(m);
+                        cv_job.wait(lock, [&] { return quit || job_id != seen; });
+                        if (quit) return;
+                        seen = job_id;
+                        mine = job;
+                    }
+                    const int code = mine(r);
+                    if (code) give_up();  // before reporting: the others may be waiting for this rank
+                    std::lock_guard<std::mutex> lock(m);
+                    rc[r] = code;
+                    if (code) err[r] = g_err;  // g_err is per thread
+                    if (--pending == 0) cv_done.notify_all();
+                }
+            });
+    } catch (...) {  // std::system_error: no more threads
+        stop();
+        return false;
+    }
+    return true;
+}
+
+void MultiGpu::run(const std::function<int(int)> &f)
+{
+    std::unique_lock<std::mutex> lock(m);
+    job = f;
+    job_id++;
+    pending = (int)workers.size();
+    for (auto &c : rc) c = 0;
+    cv_job.notify_all();
+    cv_done.wait(lock, [&] { return pending == 0; });
+    job = nullptr;
+}
+
+void MultiGpu::stop()
+{
+    {
+        std::lock_guard<std::mutex> lock(m);
+        quit = true;
+    }
+    cv_job.notify_all();
+    for (auto &t : workers)
+        if (t.joinable()) t.join();
+    workers.clear();
+}
+
+namespace {
+
+// Runs f(rank) for every rank of a multi-GPU handle, each on the rank's own host thread.
 template <typename F>
 int on_all_ranks(MultiGpu *m, F f)
 {
-    const int n = (int)m->ranks.size();
-    std::vector<int> rc(n, 0);
-    std::vector<std::string> err(n);
-    std::vector<std::thread> th;
-    for (int r = 0; r < n; r++)
-        th.emplace_back([&, r] {
-            rc[r] = f(r);
-            if (rc[r]) err[r] = g_err;  // g_err is per thread
-        });
-    for (auto &t : th) t.join();
-    for (int r = 0; r < n; r++)
-        if (rc[r]) return fail(rc[r], "rank %d: %s", r, err[r].c_str());
+    m->run(std::function<int(int)>(f));
+    for (size_t r = 0; r < m->rc.size(); r++)
+        if (m->rc[r]) return fail(m->rc[r], "rank %d: %s", (int)r, m->err[r].c_str());
     return MG_OK;
 }
 
@@ -336,6 +417,11 @@ int create_multi(const mg_config *cfg, mg_handle **out)
     }
     MultiGpu *m = h->multi;
     m->ranks.assign(n, nullptr);
+    if (!m->start(n)) {
+        delete h->multi;
+        delete h;
+        return fail(MG_ERR_NOMEM, "could not start %d host threads for the ranks", n);
+    }
     mg_dist_config dc;
     memset(&dc, 0, sizeof(dc));
     dc.base = *cfg;
@@ -356,7 +442,11 @@ int create_multi(const mg_config *cfg, mg_handle **out)
             mg_dist_config mine = dc;
             mine.rank = r;
             mine.base.device = cfg->devices[r];
-            return mg_dist_create(&mine, &m->ranks[r]);
+            mg_dist *d = nullptr;
+            const int code = mg_dist_create(&mine, &d);
+            std::lock_guard<std::mutex> lock(m->m);
+            m->ranks[r] = d;
+            return code;
         });
     if (rc) {
         mg_destroy(h);
@@ -639,6 +729,7 @@ int mg_destroy(mg_handle *h)
     if (h->multi) {
         // collective like creation: the RCCL communicators are torn down together
         on_all_ranks(h->multi, [&](int r) { return mg_dist_destroy(h->multi->ranks[r]); });
+        h->multi->stop();
         mg_local_group_destroy(h->multi->group);
         delete h->multi;
         delete h;
@@ -1436,16 +1527,29 @@ constexpr int kMaxScratchDevices = 64;
 double *g_scratch_ptr[kMaxScratchDevices];  // device address of `scratch` per device ordinal
 std::mutex g_scratch_mutex;
 
-// Device address of the current device's copy of `scratch`, looked up once per device.
-int scratch_address(double **out)
+// Device address of the copy of `scratch` on the device the stream belongs to (the current device
+// for the null stream), looked up once per device with that device current.  The first lookup on a
+// device may make the runtime load the library's code object there, which allocates the object's
+// global variables: that is why one warm-up call per device must come before a call that has to
+// be allocation free (see the header).
+int scratch_address(hipStream_t stream, double **out)
 {
-    int dev = -1;
-    HIP_TRY(hipGetDevice(&dev));
+    int cur = -1, dev = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    dev = cur;
+    if (stream) {
+        hipDevice_t sd = 0;
+        HIP_TRY(hipStreamGetDevice(stream, &sd));
+        dev = (int)sd;
+    }
     if (dev < 0 || dev >= kMaxScratchDevices) return fail(MG_ERR_INVALID, "device ordinal %d out of range", dev);
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
         void *p = nullptr;
-        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (dev != cur) HIP_TRY(hipSetDevice(dev));
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (dev != cur) HIP_TRY(hipSetDevice(cur));
+        HIP_TRY(e);
         if (!p) return fail(MG_ERR_HIP, "hipGetSymbolAddress returned a null address");
         g_scratch_ptr[dev] = (double *)p;
     }
@@ -1470,7 +1574,7 @@ int mg_dev_residual_restrict_noalloc(void *stream, const mg_dev_array *phi, cons
                         (long long)np, (long long)kNoAllocPartials);
     }
     double *ws = nullptr;
-    TRY(scratch_address(&ws));
+    TRY(scratch_address((hipStream_t)stream, &ws));
     int64_t count = 0;
     // every partial the sum reads is written by the launch before it: nothing needs clearing
     TRY(mg_dev_residual_restrict(stream, phi, b, Rc, n, c, ws, kNoAllocPartials, lo, hi, &count));

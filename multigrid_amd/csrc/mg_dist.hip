@@ -3,7 +3,8 @@
 //
 // The reference is a single-threaded CPU program (cpp/PotentialSolver.cpp:3756-4216); nothing
 // here has a counterpart in it.  What is distributed is the cycle the single-GPU handle runs,
-// operator by operator, with results bit-identical to the undivided red-black cycle:
+// operator by operator, with fields bit-identical to the undivided red-black cycle (the residual
+// norm, summed per rank and then over the ranks, agrees to rounding):
 //
 //   * the i axis (slowest; planes are contiguous, so a halo is one message) of every level
 //     l < cut is split into slabs whose fine-plane boundaries are multiples of 2^cut, so the
@@ -34,6 +35,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only; the library is bound with dlopen
 
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
@@ -70,6 +72,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;  // optional: without it a failed group cannot be released
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
@@ -94,6 +97,7 @@ const Rccl *rccl()
         BIND(GetUniqueId);
         BIND(CommInitRank);
         BIND(CommDestroy);
+        BIND(CommAbort);
         BIND(Send);
         BIND(Recv);
         BIND(AllReduce);
@@ -223,7 +227,18 @@ struct Slab {
 struct Transport {
     int rank = 0, world = 1;
     uint64_t bytes_sent = 0;
+    // Set by abort(): a rank of the group has failed.  Every later operation returns MG_ERR_COMM at
+    // once instead of queueing transfers no peer will ever match.
+    std::atomic<bool> aborted{false};
     virtual ~Transport() {}
+    // Callable from any thread, also while the rank's own thread is inside a call: gives up the
+    // group's pending and future communication so that nobody waits for a rank that is gone.
+    virtual void abort() { aborted.store(true); }
+    int alive() const
+    {
+        if (aborted.load()) return mgk::set_error(MG_ERR_COMM, "the group was given up after a rank failed");
+        return MG_OK;
+    }
     // Exchange `width` halo planes per side of `s` around the owned range `own` with the slab
     // neighbours; ordered after everything enqueued on `compute` so far.  finish() makes
     // `compute` wait for it.
@@ -255,11 +270,19 @@ struct RcclTransport : Transport {
 
     ~RcclTransport() override
     {
-        if (cs) hipStreamSynchronize(cs);
-        if (comm && api) api->CommDestroy(comm);
+        if (cs && !aborted.load()) hipStreamSynchronize(cs);
+        if (comm && api && !comm_gone.load()) api->CommDestroy(comm);
         if (to_cs) hipEventDestroy(to_cs);
         if (from_cs) hipEventDestroy(from_cs);
         if (cs) hipStreamDestroy(cs);
+    }
+    std::atomic<bool> comm_gone{false};  // ncclCommAbort has run: it frees the communicator itself
+    // ncclCommAbort ends the communicator's kernels, including those of transfers whose peer never
+    // arrives, so streams waiting on them drain and the host calls blocked on those streams return.
+    void abort() override
+    {
+        if (aborted.exchange(true)) return;
+        if (comm && api && api->CommAbort && !comm_gone.exchange(true)) api->CommAbort(comm);
     }
     int init(int rank_, int world_, const uint8_t id_bytes[MG_UNIQUE_ID_BYTES])
     {
@@ -333,6 +356,7 @@ struct RcclTransport : Transport {
     }
     int start(Slab &s, IRange own, int w, hipStream_t compute) override
     {
+        TRY(alive());
         TRY(finish(s, compute));
         if (world == 1) return MG_OK;
         if (!s.done) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
@@ -356,6 +380,7 @@ struct RcclTransport : Transport {
     }
     int finish(Slab &s, hipStream_t compute) override
     {
+        TRY(alive());
         if (!s.pending) return MG_OK;
         HIP_TRY(hipStreamWaitEvent(compute, s.done, 0));
         s.pending = false;
@@ -363,6 +388,7 @@ struct RcclTransport : Transport {
     }
     int allreduce(double *x, hipStream_t compute) override
     {
+        TRY(alive());
         if (world == 1) return MG_OK;
         TRY(order_after_compute(compute));
         NCCL_TRY(api->AllReduce(x, x, 1, ncclDouble, ncclSum, comm, cs));
@@ -370,6 +396,7 @@ struct RcclTransport : Transport {
     }
     int gather(const Plan &p, int l, bool eps, const Slab &mine, Slab *full, hipStream_t compute) override
     {
+        TRY(alive());
         if (rank == 0) TRY(copy_planes(*full, mine.v, p.own(l, eps, 0), compute));
         if (world == 1) return MG_OK;
         TRY(order_after_compute(compute));
@@ -389,6 +416,7 @@ struct RcclTransport : Transport {
     }
     int scatter(const Plan &p, int l, bool eps, const Slab *full, Slab &mine, int halo, hipStream_t compute) override
     {
+        TRY(alive());
         if (rank == 0) TRY(copy_planes(mine, full->v, p.stored(l, eps, 0, halo), compute));
         if (world == 1) return MG_OK;
         TRY(order_after_compute(compute));
@@ -451,6 +479,12 @@ namespace {
 
 struct LocalTransport : Transport {
     mg_local_group *g = nullptr;
+
+    void abort() override
+    {
+        aborted.store(true);
+        if (g) g->abandon();
+    }
 
     int meet()
     {
@@ -636,7 +670,8 @@ struct mg_dist {
         View vu = u.v, va = alt.v;
         const double *before = vu.p;
         int rc;
-        if (fold) rc = mgk::prolong_smooth_rb(stream, fold->v, correct, &vu, &va, rhs.v, n, c[l], omega, 1, r, r2);
+        // (the slabs of eps_l are zero outside 0..n_l-2 like the whole arrays: see kLoadProlongZero)
+        if (fold) rc = mgk::prolong_smooth_rb(stream, fold->v, correct, &vu, &va, rhs.v, n, c[l], omega, 1, r, r2, true);
         else rc = mgk::smooth_rb(stream, &vu, &va, rhs.v, n, c[l], omega, 1, r, r2);
         if (rc < 0) return mgk::set_error(MG_ERR_STATE, "a two-range sweep needs the out-of-place kernel");
         return vu.p != before ? 1 : 0;
@@ -1137,9 +1172,37 @@ int mg_dist_get_phi_planes(mg_dist *d, int64_t lo, int64_t hi, double *dense)
     return MG_OK;
 }
 
+namespace {
+// A rank that fails inside a collective call gives its communication up: its later calls fail at
+// once, and (in-process transport) the ranks waiting for it are released.  Ranks of an RCCL group
+// in OTHER processes are not reached by this -- their launcher ends them when this process exits
+// with the error; ranks that are threads of this process are released by mg_dist_abort on each
+// (mg_create with n_gpus does so).
+int ended(mg_dist *d, int rc)
+{
+    if (rc && d->tr) d->tr->abort();
+    return rc;
+}
+int vcycles_impl(mg_dist *d, unsigned count, double *L2);
+int solve_impl(mg_dist *d, unsigned max_it, double tol, int *converged, unsigned *cycles, double *L2);
+}  // namespace
+
 int mg_dist_vcycles(mg_dist *d, unsigned count, double *L2)
 {
     TRY(check_rank(d, true));
+    return ended(d, vcycles_impl(d, count, L2));
+}
+
+int mg_dist_solve(mg_dist *d, unsigned max_it, double tol, int *converged, unsigned *cycles, double *L2)
+{
+    TRY(check_rank(d, true));
+    return ended(d, solve_impl(d, max_it, tol, converged, cycles, L2));
+}
+
+namespace {
+
+int vcycles_impl(mg_dist *d, unsigned count, double *L2)
+{
     d->have_ef = false;
     HIP_TRY(hipEventRecord(d->ev_a, d->stream));
     for (unsigned it = 0; it < count; it++) {
@@ -1157,9 +1220,8 @@ int mg_dist_vcycles(mg_dist *d, unsigned count, double *L2)
     return MG_OK;
 }
 
-int mg_dist_solve(mg_dist *d, unsigned max_it, double tol, int *converged, unsigned *cycles, double *L2)
+int solve_impl(mg_dist *d, unsigned max_it, double tol, int *converged, unsigned *cycles, double *L2)
 {
-    TRY(check_rank(d, true));
     d->have_ef = false;
     bool conv = false;
     double l2 = 0;
@@ -1188,6 +1250,8 @@ int mg_dist_solve(mg_dist *d, unsigned max_it, double tol, int *converged, unsig
     if (L2) *L2 = l2;
     return MG_OK;
 }
+
+}  // namespace
 
 int mg_dist_compute_ef(mg_dist *d)
 {
@@ -1225,6 +1289,13 @@ int mg_dist_get_ef_planes(mg_dist *d, int64_t lo, int64_t hi, double *dense)
     HIP_TRY(hipMemcpyAsync(dense, d->ef + (size_t)(lo - o.lo) * plane, (size_t)(hi - lo) * plane * sizeof(double),
                            hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
+    return MG_OK;
+}
+
+int mg_dist_abort(mg_dist *d)
+{
+    if (!d) FAIL(MG_ERR_INVALID, "null rank handle");
+    if (d->tr) d->tr->abort();
     return MG_OK;
 }
 

@@ -178,8 +178,11 @@ void sweep_rb_fused2(hipStream_t s, View uin, View uout, View rhs, const int64_t
 // The same with the operation that precedes the sweep applied to u_in as it is loaded:
 // correct: u_in := u_in - P(ec) (fine grid, phi -= eps_h); otherwise u_in := P(ec) over
 // 0..n-2 (a coarse level's prolongated initial guess).  ec = eps of the next coarser level.
+// outside_zero (prolongation only): the caller guarantees that u_in is zero outside 0..n-2 per
+// axis (true of every eps_l the solver owns); u_in is then not read at all.
 void sweep_rb_fused_onload(hipStream_t s, View uin, View uout, View rhs, View ec, bool correct,
-                           const int64_t n[3], Coef c, double omega, IRange r, IRange r2 = IRange{0, 0});
+                           const int64_t n[3], Coef c, double omega, IRange r, IRange r2 = IRange{0, 0},
+                           bool outside_zero = false);
 // True when smooth_rb on an array of this shape (with a twin to write to) runs the out-of-place
 // single-pass kernel: disjoint plane ranges of one sweep are then independent launches.
 bool sweep_is_out_of_place(const View &u);
@@ -189,8 +192,10 @@ bool sweep_is_out_of_place(const View &u);
 bool onload_folds(const View &u, bool correct);
 // `sweeps` red-black sweeps preceded by the prolongation from ec (correct: by phi -= P(ec)):
 // fused into the first sweep where the single-pass kernel is used, separate launches otherwise.
+// outside_zero: see sweep_rb_fused_onload.
 int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, View rhs,
-                      const int64_t n[3], Coef c, double omega, int sweeps, IRange r, IRange r2 = IRange{0, 0});
+                      const int64_t n[3], Coef c, double omega, int sweeps, IRange r, IRange r2 = IRange{0, 0},
+                      bool outside_zero = false);
 // `sweeps` red-black sweeps on planes r of *u.  May ping-pong between *u and *alt (same
 // shape); on return *u is the view holding the result.  Returns the kernels launched.
 // r2: second plane range for the same (single, out-of-place) sweep; see sweep_rb_fused.

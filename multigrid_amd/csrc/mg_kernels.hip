@@ -492,14 +492,14 @@ bool onload_folds(const View &u, bool correct)
 }
 
 int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, View rhs,
-                      const int64_t n[3], Coef c, double omega, int sweeps, IRange r, IRange r2)
+                      const int64_t n[3], Coef c, double omega, int sweeps, IRange r, IRange r2, bool outside_zero)
 {
     const bool pair = r2.hi > r2.lo;
     if (pair && !(sweeps == 1 && alt && alt->p && use_fused_sweep(*u) && r2.hi - r2.lo == r.hi - r.lo &&
                   r2.lo >= r.hi))
         return -1;
     if (sweeps > 0 && alt && alt->p && onload_folds(*u, correct)) {
-        sweep_rb_fused_onload(s, *u, *alt, rhs, ec, correct, n, c, omega, r, r2);
+        sweep_rb_fused_onload(s, *u, *alt, rhs, ec, correct, n, c, omega, r, r2, outside_zero);
         View t = *u;
         *u = *alt;
         *alt = t;

@@ -143,6 +143,7 @@ SYMBOLS = {
     "mg_dist_compute_ef": (C.c_int, [C.c_void_p]),
     "mg_dist_get_ef_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
     "mg_dist_sync": (C.c_int, [C.c_void_p]),
+    "mg_dist_abort": (C.c_int, [C.c_void_p]),
     "mg_dist_stats": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_uint64)]),
 }
 
@@ -542,6 +543,10 @@ class DistRank:
 
     def sync(self):
         _check(load().mg_dist_sync(self._d))
+
+    def abort(self):
+        """Give up this rank's communication (callable from any thread): see mg_dist_abort."""
+        _check(load().mg_dist_abort(self._d))
 
     def stats(self):
         ms, sent = C.c_double(0), C.c_uint64(0)

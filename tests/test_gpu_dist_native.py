@@ -158,6 +158,44 @@ def test_rccl_transport_in_a_world_of_one(gpu, orc):
     assert_bit_equal(phi, want, "phi through the RCCL transport")
 
 
+def test_an_aborted_rccl_rank_fails_fast_and_can_be_destroyed(gpu):
+    """mg_dist_abort on an RCCL rank (ncclCommAbort through the same binding): the next collective call
+    returns MG_ERR_COMM instead of queueing transfers, and the rank can still be destroyed."""
+    from multigrid_amd import problem
+    n, depth = 65, 3
+    N = (n, n, n)
+    d = gpu.DistRank(N, problem.main_extents_dh(N), depth, 0, 1, device=0, unique_id=gpu.dist_unique_id(), coarse_cut=2)
+    try:
+        d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
+        d.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
+        assert np.isfinite(d.vcycles(1))
+        d.abort()
+        d.abort()  # idempotent
+        with pytest.raises(gpu.MgError) as e:
+            d.vcycles(1)
+        assert e.value.code == -6 and "given up" in str(e.value)
+    finally:
+        d.close()
+
+
+def test_aborting_one_rank_releases_the_ranks_waiting_for_it(gpu):
+    """Three in-process ranks; rank 1 never enters the cycle and is aborted instead (what a supervisor
+    does with a rank that failed): the others, waiting for its halo planes, return MG_ERR_COMM."""
+    def body(d, r):
+        if r == 1:
+            import time
+            time.sleep(0.5)  # the others are inside the exchange by now
+            d.abort()
+            return "aborted"
+        try:
+            d.vcycles(2)
+        except gpu.MgError as e:
+            return e.code
+        return "finished"
+
+    assert run_ranks(gpu, 3, 129, 3, 2, body, join_timeout=60) == [-6, "aborted", -6]
+
+
 def test_a_rank_alone_runs_its_share_of_a_larger_world(gpu):
     """MG_TRANSPORT_NONE: rank 1 and rank 0 of a world of four, each without peers, run the launches
     of their share (every transfer skipped) and return; the plan is that of the full world.  A

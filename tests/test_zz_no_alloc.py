@@ -66,6 +66,32 @@ def test_noalloc_equals_two_call_form_twice_in_a_row(gpu, orc):
     _run(gpu, orc, (41, 37, 45), g)   # smaller, ragged: fewer partial sums than the workspace still holds
 
 
+def test_noalloc_call_after_a_warm_up_leaves_free_memory_unchanged(gpu):
+    """After one warm-up call on the device, a call must not change the device's free memory (the
+    first call may: it can make the runtime load the library's code object, workspace included)."""
+    lib = gpu.load()
+    dev = torch.device("cuda", 0)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    n, nc = (65, 65, 65), (32, 32, 32)
+    d_phi = torch.rand((65, 65, 66), dtype=torch.float64, device=dev)
+    d_b = torch.rand((65, 65, 66), dtype=torch.float64, device=dev)
+    d_rc = torch.zeros((32, 32, 32), dtype=torch.float64, device=dev)
+    total = torch.zeros(1, dtype=torch.float64, device=dev)
+    arrs = [gpu.MgDevArray(t.data_ptr(), t.shape[0], t.shape[1], k, 0) for t, k in ((d_phi, 65), (d_b, 65), (d_rc, 32))]
+    args = [stream] + [C.byref(a) for a in arrs] + [(C.c_int64 * 3)(*n), (C.c_double * 4)(1.0, 1.0, 1.0, 6.0), 0, 65,
+                                                    C.c_void_p(total.data_ptr())]
+    gpu._check(lib.mg_dev_residual_restrict_noalloc(*args))  # warm-up
+    torch.cuda.synchronize()
+    first = float(total.item())
+    free0, _ = torch.cuda.mem_get_info(dev)
+    for _ in range(3):
+        gpu._check(lib.mg_dev_residual_restrict_noalloc(*args))
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free1 == free0
+    assert float(total.item()) == first and first > 0
+
+
 def test_noalloc_rejects_what_does_not_fit(gpu):
     lib = gpu.load()
     arr = gpu.MgDevArray(256, 4, 65535, 65535, 0)  # never dereferenced: the size check comes first
