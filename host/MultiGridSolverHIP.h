@@ -55,7 +55,7 @@ public:
     MultiGridSolverHIP(World &world, int max_it, double tol, int depth, int device = 0, bool variant_b = false);
     // The grid split into slabs of i-planes over several GPUs (one host thread per GPU inside the
     // library, halo planes over RCCL; an ordinal may repeat, e.g. {0, 0}: two slabs on one GPU).
-    // coarse_cut: first level solved whole on devices[0] (0 = the first with <= 128 planes).
+    // coarse_cut: first level every GPU holds and solves whole (0 = the first with <= 128 planes).
     // computeEF() differentiates each slab on its own GPU.
     MultiGridSolverHIP(World &world, int max_it, double tol, int depth, const std::vector<int> &devices,
                        int coarse_cut = 0);

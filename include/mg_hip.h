@@ -65,7 +65,8 @@ typedef struct mg_handle mg_handle;
  *           device-to-device copies, which lets the partitioned path run on one GPU).  Such a
  *           handle serves mg_set_rho / mg_set_phi / mg_solve / mg_vcycle(s) / mg_get_phi /
  *           mg_last_call_ms / mg_destroy; depth >= 1, flags == 0.
- *   coarse_cut  first level held whole on devices[0] (0 = the first one with <= 128 planes) */
+ *   coarse_cut  first level that is not partitioned: every GPU holds it and the coarser ones whole
+ *           and solves them itself (0 = the first one with <= 128 planes) */
 typedef struct mg_config {
     int64_t n[3];
     double dh[3];
@@ -140,7 +141,7 @@ int mg_default_config_b(mg_config *cfg, int64_t ni, int64_t nj, int64_t nk,
                         const double dh[3], int depth);
 int mg_create(const mg_config *cfg, mg_handle **out);
 /* Device memory mg_create(cfg) will allocate, in bytes: the whole set on one GPU, or with
- * n_gpus > 1 the largest share of any GPU (rank 0's: its slabs plus the whole small levels).
+ * n_gpus > 1 the largest share of any GPU (its slabs plus the whole small levels).
  * Pure arithmetic, no device needed: for choosing n_gpus before anything is allocated (2049^3
  * with seven coarse grids: 236 GB on one GPU, 30 GB per GPU on eight).  The field's array of
  * mg_compute_ef (24 bytes per fine node) is counted only with MG_FLAG_RESERVE_EF.  No counterpart
@@ -396,7 +397,7 @@ typedef struct mg_local_group mg_local_group;
 typedef struct mg_dist_config {
     mg_config base;      /* the GLOBAL grid (n, dh, depth, nu, omega); device = this rank's GPU; flags 0 */
     int32_t rank, world;
-    int32_t coarse_cut;  /* levels >= this are gathered on rank 0; 0 = first level with <= 128 planes */
+    int32_t coarse_cut;  /* levels >= this are held and solved whole by every rank; 0 = first level with <= 128 planes */
     int32_t transport;   /* MG_TRANSPORT_* */
     int32_t no_overlap;  /* 1: exchange halos after whole sweeps instead of under their interior part */
     uint8_t unique_id[MG_UNIQUE_ID_BYTES];  /* MG_TRANSPORT_RCCL */

@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmg_hip.so")
-SOURCES = ["mg_kernels.hip", "mg_sweep.hip", "mg_resrest.hip", "mg_ef.hip", "mg_api.hip", "mg_dist.hip"]
+SOURCES = ["mg_kernels.hip", "mg_sweep.hip", "mg_tile.hip", "mg_resrest.hip", "mg_ef.hip", "mg_api.hip", "mg_dist.hip"]
 HEADERS = [os.path.join(CSRC, "mg_kernels.h"), os.path.join(CSRC, "mg_internal.h"),
            os.path.join(HERE, "..", "include", "mg_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",

@@ -17,9 +17,13 @@
 //     neighbour, (2) start of the exchange of exactly those planes on the communication stream,
 //     (3) the interior -- which reads no halo plane of the previous sweep -- and the next reader
 //     of the halos waits for the transfer.  The fine residual+restriction is split the same way;
-//   * the sum of squared residuals is all-reduced once per cycle;
-//   * level `cut` and everything below it is gathered onto rank 0, solved there on whole arrays
-//     with the single-GPU kernels, and eps_cut is scattered back.
+//   * the sum of squared residuals is all-reduced once per cycle, beside the kernels: nothing on the
+//     kernel stream waits for it but the next writer of the sum and the host's read of it;
+//   * R of level `cut` is all-gathered and EVERY rank solves level `cut` and everything below it on
+//     whole arrays of its own with the single-GPU kernels.  Those levels are serial work of the
+//     cycle whoever runs them (everything after them waits for eps_cut); run on all ranks at once
+//     they cost what they cost on one, no rank idles and then receives, and eps_cut needs no
+//     transfer at all: each rank prolongs from its own copy.
 //
 // Transports: RCCL (ncclSend/ncclRecv/ncclAllReduce on a stream of its own, ordered against the
 // kernel stream with events; librccl is loaded on first use, so single-GPU users never need
@@ -157,30 +161,11 @@ struct Plan {
         bounds.assign(world + 1, 0);
         bounds[world] = n0[0];
         if (world == 1) return MG_OK;
-        // Rank 0 also runs the gathered levels cut..L while the others wait, so it owns fewer units
-        // when a unit is cheap enough for that to shorten the slowest rank's cycle.  Both costs are
-        // estimates from measurements on MI355X (a slab rank's whole cycle per fine point; the
-        // gathered levels, which are launch bound and about the same for every grid): the choice
-        // only shifts work between ranks, never the result.
-        const double t_unit = (double)align * (double)n0[1] * (double)n0[2] * 17e-12;
-        const double t_tail = 60e-6 * (depth - cut + 1) + 20e-6;
-        int64_t relief = 0;
-        double best = (double)even * t_unit + t_tail;
-        for (int64_t r = 1; r <= even / 4; r++) {
-            const int64_t rest = units - (even - r), most = (rest + world - 2) / (world - 1);
-            const double mine = (double)(even - r) * t_unit + t_tail, theirs = (double)most * t_unit;
-            const double cost = mine > theirs ? mine : theirs;
-            if (cost < best * (1 - 1e-9)) {
-                best = cost;
-                relief = r;
-            }
-        }
-        // ranks 1..world-1 share what is left as evenly as whole units allow, the spare units going to
-        // the lower ranks (the last rank also takes the planes beyond the last whole unit)
-        const int64_t first = even - relief, rest = units - first;
-        const int64_t each = rest / (world - 1), spare = rest % (world - 1);
-        bounds[1] = first * align;
-        for (int r = 2; r < world; r++) bounds[r] = bounds[r - 1] + (each + (r - 1 <= spare ? 1 : 0)) * align;
+        // Whole units as evenly as they go, the spare ones to the lower ranks (the last rank also
+        // takes the planes beyond the last whole unit).  No rank is given less for running the
+        // levels below the cut: every rank runs them, at the same time.
+        const int64_t spare = units % world;
+        for (int r = 1; r < world; r++) bounds[r] = bounds[r - 1] + (even + (r - 1 < spare ? 1 : 0)) * align;
         return MG_OK;
     }
     void level_n(int l, int64_t out[3]) const
@@ -244,12 +229,13 @@ struct Transport {
     // `compute` wait for it.
     virtual int start(Slab &s, IRange own, int width, hipStream_t compute) = 0;
     virtual int finish(Slab &s, hipStream_t compute) = 0;
-    // *dev_scalar = sum over ranks, same bits on every rank
+    // *dev_scalar = sum over ranks, same bits on every rank; ordered after everything enqueued on
+    // `compute` so far.  `compute` itself does not wait: sum_ready() makes it, and must precede the
+    // next write and every read of the scalar.
     virtual int allreduce(double *dev_scalar, hipStream_t compute) = 0;
-    // owned planes of level-l array `mine` of every rank -> rank 0's whole array
-    virtual int gather(const Plan &p, int l, bool eps, const Slab &mine, Slab *full, hipStream_t compute) = 0;
-    // rank 0's whole array -> every rank's stored planes (owned + halo)
-    virtual int scatter(const Plan &p, int l, bool eps, const Slab *full, Slab &mine, int halo, hipStream_t compute) = 0;
+    virtual int sum_ready(hipStream_t compute) = 0;
+    // owned planes of level-l array `mine` of every rank -> every rank's whole array `full`
+    virtual int allgather(const Plan &p, int l, bool eps, const Slab &mine, Slab &full, hipStream_t compute) = 0;
 };
 
 int copy_planes(Slab &dst, const View &src, IRange r, hipStream_t s)
@@ -274,6 +260,7 @@ struct RcclTransport : Transport {
         if (comm && api && !comm_gone.load()) api->CommDestroy(comm);
         if (to_cs) hipEventDestroy(to_cs);
         if (from_cs) hipEventDestroy(from_cs);
+        if (sum_done) hipEventDestroy(sum_done);
         if (cs) hipStreamDestroy(cs);
     }
     std::atomic<bool> comm_gone{false};  // ncclCommAbort has run: it frees the communicator itself
@@ -304,7 +291,7 @@ struct RcclTransport : Transport {
         NCCL_TRY(api->CommInitRank(&comm, world, id, rank));
         // A world of one never exchanges anything; what it can do is prove that the library was
         // bound correctly and that its calls run on the communication stream the way start(),
-        // allreduce() and gather() issue them.
+        // allreduce() and allgather() issue them.
         if (world == 1) TRY(loopback_check());
         return MG_OK;
     }
@@ -386,50 +373,41 @@ struct RcclTransport : Transport {
         s.pending = false;
         return MG_OK;
     }
+    hipEvent_t sum_done = nullptr;
+    bool sum_pending = false;
     int allreduce(double *x, hipStream_t compute) override
     {
         TRY(alive());
         if (world == 1) return MG_OK;
+        if (!sum_done) HIP_TRY(hipEventCreateWithFlags(&sum_done, hipEventDisableTiming));
         TRY(order_after_compute(compute));
         NCCL_TRY(api->AllReduce(x, x, 1, ncclDouble, ncclSum, comm, cs));
-        return compute_waits(compute);
+        HIP_TRY(hipEventRecord(sum_done, cs));
+        sum_pending = true;
+        return MG_OK;
     }
-    int gather(const Plan &p, int l, bool eps, const Slab &mine, Slab *full, hipStream_t compute) override
+    int sum_ready(hipStream_t compute) override
+    {
+        if (!sum_pending) return MG_OK;
+        HIP_TRY(hipStreamWaitEvent(compute, sum_done, 0));
+        sum_pending = false;
+        return MG_OK;
+    }
+    int allgather(const Plan &p, int l, bool eps, const Slab &mine, Slab &full, hipStream_t compute) override
     {
         TRY(alive());
-        if (rank == 0) TRY(copy_planes(*full, mine.v, p.own(l, eps, 0), compute));
+        const IRange me = p.own(l, eps, rank);
+        TRY(copy_planes(full, mine.v, me, compute));
         if (world == 1) return MG_OK;
         TRY(order_after_compute(compute));
+        // grouped send/recv pairs rather than ncclAllGather: the ranks' shares differ in length
         NCCL_TRY(api->GroupStart());
-        if (rank == 0) {
-            for (int r = 1; r < world; r++) {
-                const IRange o = p.own(l, eps, r);
-                NCCL_TRY(api->Recv(full->plane(o.lo), (size_t)(o.hi - o.lo) * full->v.si, ncclDouble, r, comm, cs));
-            }
-        } else {
-            const IRange o = p.own(l, eps, rank);
-            NCCL_TRY(api->Send(mine.plane(o.lo), (size_t)(o.hi - o.lo) * mine.v.si, ncclDouble, 0, comm, cs));
-            bytes_sent += (uint64_t)(o.hi - o.lo) * mine.v.si * 8;
-        }
-        NCCL_TRY(api->GroupEnd());
-        return compute_waits(compute);
-    }
-    int scatter(const Plan &p, int l, bool eps, const Slab *full, Slab &mine, int halo, hipStream_t compute) override
-    {
-        TRY(alive());
-        if (rank == 0) TRY(copy_planes(mine, full->v, p.stored(l, eps, 0, halo), compute));
-        if (world == 1) return MG_OK;
-        TRY(order_after_compute(compute));
-        NCCL_TRY(api->GroupStart());
-        if (rank == 0) {
-            for (int r = 1; r < world; r++) {
-                const IRange o = p.stored(l, eps, r, halo);
-                NCCL_TRY(api->Send(full->plane(o.lo), (size_t)(o.hi - o.lo) * full->v.si, ncclDouble, r, comm, cs));
-                bytes_sent += (uint64_t)(o.hi - o.lo) * full->v.si * 8;
-            }
-        } else {
-            const IRange o = p.stored(l, eps, rank, halo);
-            NCCL_TRY(api->Recv(mine.plane(o.lo), (size_t)(o.hi - o.lo) * mine.v.si, ncclDouble, 0, comm, cs));
+        for (int r = 0; r < world; r++) {
+            if (r == rank) continue;
+            const IRange o = p.own(l, eps, r);
+            NCCL_TRY(api->Send(mine.plane(me.lo), (size_t)(me.hi - me.lo) * mine.v.si, ncclDouble, r, comm, cs));
+            NCCL_TRY(api->Recv(full.plane(o.lo), (size_t)(o.hi - o.lo) * full.v.si, ncclDouble, r, comm, cs));
+            bytes_sent += (uint64_t)(me.hi - me.lo) * mine.v.si * 8;
         }
         NCCL_TRY(api->GroupEnd());
         return compute_waits(compute);
@@ -550,34 +528,23 @@ struct LocalTransport : Transport {
         if (world == 1) return MG_OK;
         return guard(allreduce_now(x, compute));
     }
-    int gather_now(const Plan &p, int l, bool eps, const Slab &mine, Slab *full, hipStream_t compute)
+    int sum_ready(hipStream_t) override { return MG_OK; }
+    int allgather_now(const Plan &p, int l, bool eps, const Slab &mine, Slab &full, hipStream_t compute)
     {
         HIP_TRY(hipStreamSynchronize(compute));
         g->post[rank] = &mine.v;
         TRY(meet());
-        if (rank == 0)
-            for (int r = 0; r < world; r++) TRY(copy_planes(*full, *g->post[r], p.own(l, eps, r), compute));
+        for (int r = 0; r < world; r++) {
+            TRY(copy_planes(full, *g->post[r], p.own(l, eps, r), compute));
+            if (r != rank) bytes_sent += (uint64_t)(p.own(l, eps, rank).hi - p.own(l, eps, rank).lo) * mine.v.si * 8;
+        }
         HIP_TRY(hipStreamSynchronize(compute));
         return meet();
     }
-    int gather(const Plan &p, int l, bool eps, const Slab &mine, Slab *full, hipStream_t compute) override
+    int allgather(const Plan &p, int l, bool eps, const Slab &mine, Slab &full, hipStream_t compute) override
     {
-        if (world == 1) return copy_planes(*full, mine.v, p.own(l, eps, 0), compute);
-        return guard(gather_now(p, l, eps, mine, full, compute));
-    }
-    int scatter_now(const Plan &p, int l, bool eps, const Slab *full, Slab &mine, int halo, hipStream_t compute)
-    {
-        HIP_TRY(hipStreamSynchronize(compute));
-        if (rank == 0) g->post[0] = &full->v;
-        TRY(meet());
-        TRY(copy_planes(mine, *g->post[0], p.stored(l, eps, rank, halo), compute));
-        HIP_TRY(hipStreamSynchronize(compute));
-        return meet();
-    }
-    int scatter(const Plan &p, int l, bool eps, const Slab *full, Slab &mine, int halo, hipStream_t compute) override
-    {
-        if (world == 1) return copy_planes(mine, full->v, p.stored(l, eps, 0, halo), compute);
-        return guard(scatter_now(p, l, eps, full, mine, halo, compute));
+        if (world == 1) return copy_planes(full, mine.v, p.own(l, eps, 0), compute);
+        return guard(allgather_now(p, l, eps, mine, full, compute));
     }
 };
 
@@ -590,13 +557,10 @@ struct SoloTransport : Transport {
     int start(Slab &, IRange, int, hipStream_t) override { return MG_OK; }
     int finish(Slab &, hipStream_t) override { return MG_OK; }
     int allreduce(double *, hipStream_t) override { return MG_OK; }
-    int gather(const Plan &p, int l, bool eps, const Slab &mine, Slab *full, hipStream_t compute) override
+    int sum_ready(hipStream_t) override { return MG_OK; }
+    int allgather(const Plan &p, int l, bool eps, const Slab &mine, Slab &full, hipStream_t compute) override
     {
-        return rank == 0 ? copy_planes(*full, mine.v, p.own(l, eps, 0), compute) : MG_OK;
-    }
-    int scatter(const Plan &p, int l, bool eps, const Slab *full, Slab &mine, int halo, hipStream_t compute) override
-    {
-        return rank == 0 ? copy_planes(mine, full->v, p.stored(l, eps, 0, halo), compute) : MG_OK;
+        return copy_planes(full, mine.v, p.own(l, eps, rank), compute);
     }
 };
 
@@ -617,8 +581,8 @@ struct mg_dist {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     Transport *tr = nullptr;
     Slab phi, phi_alt, b;
-    Slab R[MG_MAX_LEVELS], eps[MG_MAX_LEVELS], eps_alt[MG_MAX_LEVELS];     // distributed levels 1..cut
-    Slab cR[MG_MAX_LEVELS], ceps[MG_MAX_LEVELS], ceps_alt[MG_MAX_LEVELS];  // whole levels cut..L, rank 0 only
+    Slab R[MG_MAX_LEVELS], eps[MG_MAX_LEVELS], eps_alt[MG_MAX_LEVELS];     // slabs: R of levels 1..cut, eps of 1..cut-1
+    Slab cR[MG_MAX_LEVELS], ceps[MG_MAX_LEVELS], ceps_alt[MG_MAX_LEVELS];  // whole levels cut..L, on every rank
     std::vector<void *> blocks;  // every device allocation of this rank
     double *partials = nullptr;
     int64_t n_partials = 0;
@@ -650,6 +614,9 @@ struct mg_dist {
         return MG_OK;
     }
     IRange own(int l, bool eps_kind) const { return plan.own(l, eps_kind, rank); }
+    // eps of level l as the level above prolongs from it: this rank's slab, or for the first whole
+    // level the rank's own copy of the whole array
+    Slab &eps_of(int l) { return l >= cut ? ceps[l] : eps[l]; }
 
     // plane ranges of an owned slab: the two planes next to each existing neighbour (what a halo
     // exchange of width 2 sends) and the interior between them
@@ -749,9 +716,9 @@ struct mg_dist {
     {
         if (!correction_pending) return MG_OK;
         // on every stored plane, halos included: eps_1's halos are current
-        TRY(tr->finish(eps[1], stream));
+        TRY(tr->finish(eps_of(1), stream));
         TRY(tr->finish(phi, stream));
-        mgk::prolong_correct(stream, eps[1].v, phi.v, plan.n0, plan.stored(0, false, rank, H_U));
+        mgk::prolong_correct(stream, eps_of(1).v, phi.v, plan.n0, plan.stored(0, false, rank, H_U));
         HIP_TRY(hipGetLastError());
         correction_pending = false;
         return MG_OK;
@@ -762,7 +729,7 @@ struct mg_dist {
     int smooth_and_residual()
     {
         if (correction_pending && nu[0] > 0) {
-            TRY(sweeps(0, &eps[1], true));  // step 6) of the previous iteration rides along
+            TRY(sweeps(0, &eps_of(1), true));  // step 6) of the previous iteration rides along
             correction_pending = false;
         } else {
             TRY(flush_correction());
@@ -797,14 +764,15 @@ struct mg_dist {
                                    parts2[idx]);
             used += np;
         }
+        TRY(tr->sum_ready(stream));  // the previous cycle's all-reduce has read the scalar
         mgk::sum_partials(stream, partials, used, d_sum);
         HIP_TRY(hipGetLastError());
         TRY(tr->finish(phi, stream));
         return tr->allreduce(d_sum, stream);
     }
 
-    // Levels cut..L on whole arrays (rank 0): restrict down, smooth the coarsest, (prolong,
-    // smooth) back up to level `cut`.
+    // Levels cut..L on whole arrays (every rank its own): restrict down, smooth the coarsest,
+    // (prolong, smooth) back up to level `cut`.
     int coarse_levels()
     {
         int64_t n[3];
@@ -824,32 +792,40 @@ struct mg_dist {
         return MG_OK;
     }
 
-    // Steps 3)-5): restrict down to the cut level, gather, solve the small levels on rank 0,
-    // scatter, then (prolong, smooth) up.  Step 6), the correction of phi, is left pending for the
+    // Steps 3)-5): restrict down to the cut level, all-gather it, solve the whole levels (every
+    // rank), then (prolong, smooth) up.  Step 6), the correction of phi, is left pending for the
     // next iteration's first sweep.
     int coarse_correction()
     {
         int64_t n[3];
         for (int l = 1; l < cut; l++) {
             // R_l's halo plane below feeds the restriction; both feed the sweeps' red halo planes
-            TRY(tr->start(R[l], own(l, false), H_RHS, stream));
-            TRY(tr->finish(R[l], stream));
             plan.level_n(l, n);
-            mgk::restrict27(stream, R[l].v, R[l + 1].v, n, own(l + 1, false));
+            const IRange oc = own(l + 1, false);
+            TRY(tr->start(R[l], own(l, false), H_RHS, stream));
+            if (world > 1 && overlap && rank > 0 && oc.hi - oc.lo >= 2) {
+                // only the first coarse plane reads the halo plane: the others go first, under the exchange
+                mgk::restrict27(stream, R[l].v, R[l + 1].v, n, IRange{oc.lo + 1, oc.hi});
+                TRY(tr->finish(R[l], stream));
+                mgk::restrict27(stream, R[l].v, R[l + 1].v, n, IRange{oc.lo, oc.lo + 1});
+            } else {
+                TRY(tr->finish(R[l], stream));
+                mgk::restrict27(stream, R[l].v, R[l + 1].v, n, oc);
+            }
         }
         HIP_TRY(hipGetLastError());
-        TRY(tr->gather(plan, cut, false, R[cut], rank == 0 ? &cR[cut] : nullptr, stream));
-        if (rank == 0) TRY(coarse_levels());
-        TRY(tr->scatter(plan, cut, true, rank == 0 ? &ceps[cut] : nullptr, eps[cut], H_U, stream));
+        TRY(tr->allgather(plan, cut, false, R[cut], cR[cut], stream));
+        TRY(coarse_levels());
         for (int l = cut - 1; l >= 1; l--) {
+            Slab &below = eps_of(l + 1);
             if (nu[l] > 0) {
                 // eps_l = P(eps_{l+1}) as the first sweep's input, on halo planes too (eps_{l+1}'s
-                // halos are current), so the prolongation needs no exchange of its own
-                TRY(sweeps(l, &eps[l + 1], false));
+                // halos are current, or it is a whole array), so the prolongation needs no exchange
+                TRY(sweeps(l, &below, false));
             } else {
-                TRY(tr->finish(eps[l + 1], stream));
+                TRY(tr->finish(below, stream));
                 plan.level_n(l, n);
-                mgk::prolong(stream, eps[l + 1].v, eps[l].v, n, plan.stored(l, true, rank, H_U));
+                mgk::prolong(stream, below.v, eps[l].v, n, plan.stored(l, true, rank, H_U));
                 HIP_TRY(hipGetLastError());
             }
         }
@@ -859,6 +835,7 @@ struct mg_dist {
 
     int read_sum(double *out)
     {
+        TRY(tr->sum_ready(stream));
         HIP_TRY(hipMemcpyAsync(h_sum, d_sum, sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         *out = *h_sum;
@@ -922,11 +899,10 @@ long long mgk::dist_rank_device_bytes(const long long n_[3], int depth, int worl
     long long sum = 2 * bytes(0, false, P.stored(0, false, rank, H_U)) + bytes(0, false, P.stored(0, false, rank, H_RHS));
     for (int l = 1; l <= P.cut; l++) {
         sum += bytes(l, false, P.stored(l, false, rank, H_RHS));
-        sum += (l < P.cut ? 2 : 1) * bytes(l, true, P.stored(l, true, rank, H_U));
+        if (l < P.cut) sum += 2 * bytes(l, true, P.stored(l, true, rank, H_U));
     }
-    if (rank == 0)
-        for (int l = P.cut; l <= depth; l++)
-            sum += bytes(l, false, IRange{0, P.planes(l, false)}) + 2 * bytes(l, true, IRange{0, P.planes(l, true)});
+    for (int l = P.cut; l <= depth; l++)
+        sum += bytes(l, false, IRange{0, P.planes(l, false)}) + 2 * bytes(l, true, IRange{0, P.planes(l, true)});
     const IRange o = P.own(0, false, rank);
     sum += (mgk::residual_restrict_partials(n, o) + 2 * mgk::residual_restrict_partials(n, IRange{o.lo, o.lo + 2}) + 1) *
            (long long)sizeof(double);  // an upper bound of the partial sums of the split residual pass
@@ -1081,15 +1057,16 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
     CREATE_TRY(d->alloc(&d->b, 0, false, P.stored(0, false, r, H_RHS)));
     for (int l = 1; l <= d->cut; l++) {
         CREATE_TRY(d->alloc(&d->R[l], l, false, P.stored(l, false, r, H_RHS)));
-        CREATE_TRY(d->alloc(&d->eps[l], l, true, P.stored(l, true, r, H_U)));
-        if (l < d->cut) CREATE_TRY(d->alloc(&d->eps_alt[l], l, true, P.stored(l, true, r, H_U)));
-    }
-    if (r == 0)
-        for (int l = d->cut; l <= d->L; l++) {
-            CREATE_TRY(d->alloc(&d->cR[l], l, false, IRange{0, P.planes(l, false)}));
-            CREATE_TRY(d->alloc(&d->ceps[l], l, true, IRange{0, P.planes(l, true)}));
-            CREATE_TRY(d->alloc(&d->ceps_alt[l], l, true, IRange{0, P.planes(l, true)}));
+        if (l < d->cut) {
+            CREATE_TRY(d->alloc(&d->eps[l], l, true, P.stored(l, true, r, H_U)));
+            CREATE_TRY(d->alloc(&d->eps_alt[l], l, true, P.stored(l, true, r, H_U)));
         }
+    }
+    for (int l = d->cut; l <= d->L; l++) {
+        CREATE_TRY(d->alloc(&d->cR[l], l, false, IRange{0, P.planes(l, false)}));
+        CREATE_TRY(d->alloc(&d->ceps[l], l, true, IRange{0, P.planes(l, true)}));
+        CREATE_TRY(d->alloc(&d->ceps_alt[l], l, true, IRange{0, P.planes(l, true)}));
+    }
     {
         // partial sums of the fine residual: the owned range, or interior + edges
         const IRange o = d->own(0, false);

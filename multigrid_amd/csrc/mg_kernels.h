@@ -75,7 +75,8 @@ struct WgOrder {
 bool wg_order_blocked();
 
 // Row pitch used for every device array: rows start 16-byte aligned.
-inline int64_t pitch_for(int64_t nk) { return (nk + 1) & ~int64_t(1); }
+int64_t pitch_for(int64_t nk);
+int exp_knob(const char *name, int dflt);  // experiment switches from the environment (read once each)
 
 // Stencil coefficients of a level: 1/h^2 per axis, d = 2cx+2cy+2cz, and what div_d() needs.
 struct Coef {
@@ -183,7 +184,11 @@ void sweep_rb_fused2(hipStream_t s, View uin, View uout, View rhs, const int64_t
 void sweep_rb_fused_onload(hipStream_t s, View uin, View uout, View rhs, View ec, bool correct,
                            const int64_t n[3], Coef c, double omega, IRange r, IRange r2 = IRange{0, 0},
                            bool outside_zero = false);
-// True when smooth_rb on an array of this shape (with a twin to write to) runs the out-of-place
+// The same by 3-D tiles instead of a march along i (mg_tile.hip): for levels with short rows and
+// for plane ranges too short to march along.  Same contract as sweep_rb_fused.
+void sweep_rb_tile(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c, double omega,
+                   IRange r, IRange r2 = IRange{0, 0});
+// True when smooth_rb on an array of this shape (with a twin to write to) runs an out-of-place
 // single-pass kernel: disjoint plane ranges of one sweep are then independent launches.
 bool sweep_is_out_of_place(const View &u);
 // True when prolong_smooth_rb folds the prolongation (correct: the correction) into the loads of

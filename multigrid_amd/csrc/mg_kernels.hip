@@ -9,6 +9,7 @@
 #include "mg_kernels.h"
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 
 namespace mgk {
@@ -350,6 +351,24 @@ Coef make_coef(double cx, double cy, double cz, double d)
     return c;
 }
 
+int exp_knob(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+int64_t pitch_for(int64_t nk)
+{
+    static const int mode = exp_knob("MG_EXP_PITCH", 0);
+    if (mode == 1 && nk >= 192) {  // an odd multiple of 256 bytes: consecutive rows start one channel apart
+        int64_t p = (nk + 31) / 32;
+        if (!(p & 1)) p++;
+        return p * 32;
+    }
+    if (mode > 1 && nk >= 192) return ((nk + 1) & ~int64_t(1)) + mode;
+    return (nk + 1) & ~int64_t(1);
+}
+
 namespace {
 
 inline dim3 grid_for(int64_t nk, int64_t nj, int64_t ni)
@@ -408,16 +427,27 @@ static bool use_fused_sweep(const View &u) { return u.d[0] >= 4 && u.d[1] >= 128
 // fine sweep 18 % more read traffic.
 bool wg_order_blocked() { return true; }
 
-bool sweep_is_out_of_place(const View &u) { return use_fused_sweep(u); }
+// Plane ranges up to this length go to the tile kernel even where the marching kernel could run (the
+// two planes next to a slab neighbour: a march over them is all lead-in planes and start-up).
+// Measured on 32 planes of 257^2 / 513^2: the march 14 / 36 us, tiles 21 / 71 us; on 2 planes of
+// 257^2: the march 8 us, tiles 4 us.
+static int tile_max_planes()
+{
+    static const int v = exp_knob("MG_EXP_TILE_PLANES", 2);
+    return v;
+}
+static bool use_tile_sweep() { static const int v = exp_knob("MG_EXP_NO_TILE", 0); return v == 0; }
+
+bool sweep_is_out_of_place(const View &u) { return use_fused_sweep(u) || (use_tile_sweep() && u.d[0] >= 1); }
 
 int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c,
               double omega, int sweeps, IRange r, IRange r2)
 {
     if (n[0] < 3 || n[1] < 3 || n[2] < 3) return 0;
     const bool pair = r2.hi > r2.lo;
-    if (pair && !(sweeps == 1 && alt && alt->p && use_fused_sweep(*u) && r2.hi - r2.lo == r.hi - r.lo &&
+    if (pair && !(sweeps == 1 && alt && alt->p && sweep_is_out_of_place(*u) && r2.hi - r2.lo == r.hi - r.lo &&
                   r2.lo >= r.hi))
-        return -1;  // a second range needs the out-of-place kernel and one sweep
+        return -1;  // a second range needs an out-of-place kernel and one sweep
     const bool whole = !pair && u->i0 == 0 && r.lo == 0 && r.hi == u->d[0] && rhs.i0 == 0;
     // small enough for one workgroup: all sweeps in a single launch, u in LDS, <= 4 points per
     // colour per thread in registers
@@ -445,7 +475,8 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
                                (int)n[2], c, omega, sweeps);
         return 1;
     }
-    const bool fused = alt && alt->p && use_fused_sweep(*u);
+    const bool tile = alt && alt->p && use_tile_sweep() && (!use_fused_sweep(*u) || r.hi - r.lo <= tile_max_planes());
+    const bool fused = !tile && alt && alt->p && use_fused_sweep(*u);
     // two sweeps per launch where the stored planes reach four beyond the range (always, for a
     // whole array; a slab with two halo planes exchanges between sweeps instead)
     const auto holds = [&](const View &v, int64_t lo, int64_t hi, int64_t top) {
@@ -461,8 +492,9 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
             *u = *alt;
             *alt = t;
             sw++;
-        } else if (fused) {
-            sweep_rb_fused(s, *u, *alt, rhs, n, c, omega, r, r2);
+        } else if (fused || tile) {
+            if (tile) sweep_rb_tile(s, *u, *alt, rhs, n, c, omega, r, r2);
+            else sweep_rb_fused(s, *u, *alt, rhs, n, c, omega, r, r2);
             View t = *u;
             *u = *alt;
             *alt = t;
@@ -495,7 +527,7 @@ int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, 
                       const int64_t n[3], Coef c, double omega, int sweeps, IRange r, IRange r2, bool outside_zero)
 {
     const bool pair = r2.hi > r2.lo;
-    if (pair && !(sweeps == 1 && alt && alt->p && use_fused_sweep(*u) && r2.hi - r2.lo == r.hi - r.lo &&
+    if (pair && !(sweeps == 1 && alt && alt->p && sweep_is_out_of_place(*u) && r2.hi - r2.lo == r.hi - r.lo &&
                   r2.lo >= r.hi))
         return -1;
     if (sweeps > 0 && alt && alt->p && onload_folds(*u, correct)) {

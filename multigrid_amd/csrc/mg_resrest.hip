@@ -326,6 +326,8 @@ Geometry geometry(const int64_t n[3], IRange r, IRange r2 = IRange{0, 0})
     } else {
         int nchunks = pick_chunks((int64_t)g.tiles_j * g.tiles_k, planes, 3, 2, window_rows(n) == 64 ? 256 : 512,
                                   !blocked);
+        static const int forced = exp_knob("MG_EXP_CHUNKS_RES", 0);
+        if (forced > 0 && planes >= 100) nchunks = forced;
         int CI = (int)((planes + nchunks - 1) / nchunks);
         CI += CI & 1;  // chunks start on even planes: a coarse plane's three fine planes stay together
         g.nchunks = nchunks;

@@ -640,6 +640,8 @@ static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec
     const int tiles = tiles_j * tiles_k;
     const bool blocked = wg_order_blocked();
     int nchunks = pick_chunks(tiles, planes, 4, 1, WJ == 32 ? 512 : 256, !blocked);
+    static const int forced = exp_knob("MG_EXP_CHUNKS_SWEEP", 0);
+    if (forced > 0 && planes >= 100) nchunks = forced;
     int CI = (int)((planes + nchunks - 1) / nchunks);
     int cstride = CI, rhi = (int)r.hi;
     if (r2.hi > r2.lo) {

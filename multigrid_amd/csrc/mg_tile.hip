@@ -1,0 +1,184 @@
+// Red-black GS-SOR sweep by 3-D tiles: both colours in ONE launch, out of place, for the arrays
+// the marching kernels of mg_sweep.hip serve badly -- levels with fewer than 128 rows (where a
+// colour-per-launch smoother costs two dependent launches per sweep and each launch is pure
+// latency) and plane ranges too short to march along.
+//
+// A workgroup owns a TI x TJ x TK block of points.  It loads the block plus two rings of u_in,
+// updates the red points of the block plus ONE ring (their black neighbours are old values, all
+// inside the loaded region), then, after a barrier, the black points of the block itself (their red
+// neighbours are the values just computed), and stores the block to u_out.  The red values of the
+// ring are computed redundantly by the neighbouring workgroups -- from the same operands with the
+// same expression, hence to the same bits -- which is what removes the kernel boundary between the
+// colours.  Points outside 1..n-2 are copied through.
+//
+// Thread mapping: the loaded region is BI x 16 x 32 (BI = TI + 4, 16 = TJ + 4 rows, 32 = TK + 4
+// columns = 16 aligned pairs).  Thread (row, pair) of the 256 keeps its pair of every one of the BI
+// planes in registers: the i-1 / i+1 neighbours of a point are the thread's own registers, the
+// other element of the pair is its k-1 or k+1 neighbour, and only the j-1 / j+1 neighbours and the
+// adjacent pair's element come from the LDS image, whose two pair elements are stored apart
+// ([element][plane][row][pair]: consecutive lanes read consecutive words).  All index arithmetic is
+// shifts and masks.
+//
+// The update is the reference's expression evaluated in its order
+// (cpp/PotentialSolver.cpp:3780-3786, :3929-3935): results are bit-identical to the
+// colour-per-launch kernel and to the marching kernels.
+#include "mg_kernels.h"
+
+#include <type_traits>
+
+namespace mgk {
+
+namespace {
+
+struct alignas(16) d2 { double x, y; };
+
+__device__ __forceinline__ double pick(d2 v, int e) { return e ? v.y : v.x; }
+
+constexpr int kTileJ = 12, kTileK = 28;  // owned rows / columns of a tile; + 4 = 16 rows, 16 pairs
+
+template <int TI>
+__global__ __launch_bounds__(256) void k_sweep_tile(View uin, View uout, View rhs, int nI, int nJ, int nK, Coef c,
+                                                     double omega, int tiles_j, int tiles_k, int tiles_i1, int lo1,
+                                                     int hi1, int lo2, int hi2)
+{
+    constexpr int BI = TI + 4, BJ = kTileJ + 4, H = (kTileK + 4) / 2;
+    static_assert(BJ == 16 && H == 16, "thread mapping: 16 rows of 16 pairs");
+    constexpr int PLANE = BJ * H;            // pairs per plane of the region = threads
+    constexpr int ELEM = BI * PLANE + 2;     // one pair element of the region, a guard word at either end
+    __shared__ double su[2 * ELEM];
+
+    const int tid = threadIdx.x;
+    const int lkp = tid & 15, lj = tid >> 4;
+    int b = blockIdx.x;
+    const int tk = b % tiles_k;
+    b /= tiles_k;
+    const int tj = b % tiles_j;
+    int ti = b / tiles_j;
+    int rlo = lo1, rhi = hi1;
+    if (ti >= tiles_i1) {  // second plane range of the launch
+        ti -= tiles_i1;
+        rlo = lo2;
+        rhi = hi2;
+    }
+    const int gi0 = rlo + ti * TI - 2, gj = tj * kTileJ - 2 + lj, gk = tk * kTileK - 2 + 2 * lkp;  // gk: the pair's even element
+    const int own_hi = min(rlo + ti * TI + TI, rhi);  // owned planes: [gi0 + 2, own_hi)
+    const int uJ = (int)uin.d[1], uK = (int)uin.d[2];
+    const int rJ = (int)rhs.d[1], rK = (int)rhs.d[2];
+    const int ulo = (int)uin.i0, uhi = (int)uin.i_end() - 1;
+    const int blo = (int)rhs.i0, bhi = (int)rhs.i_end() - 1;
+
+    // Every global load is requested before anything waits, unconditionally and with clamped
+    // coordinates (a branch around a load makes the compiler wait for it on the spot); a point that
+    // is not updated never uses what was fetched for it.
+    d2 v[BI], rb[BI];
+    {
+        const int64_t ou = (int64_t)min(max(gj, 0), uJ - 1) * uin.sj + min(max(gk, 0), (uK - 1) & ~1);
+        const int64_t ob = (int64_t)min(max(gj, 0), rJ - 1) * rhs.sj + min(max(gk, 0), (rK - 1) & ~1);
+#pragma unroll
+        for (int q = 0; q < BI; q++)
+            v[q] = *reinterpret_cast<const d2 *>(uin.p + (int64_t)(min(max(gi0 + q, ulo), uhi) - ulo) * uin.si + ou);
+#pragma unroll
+        for (int q = 1; q < BI - 1; q++)
+            rb[q] = *reinterpret_cast<const d2 *>(rhs.p + (int64_t)(min(max(gi0 + q, blo), bhi) - blo) * rhs.si + ob);
+    }
+    // which points of this thread's column of pairs may be updated at all (interior of the level):
+    // element x at gk, y at gk + 1
+    const bool jin = gj >= 1 && gj <= nJ - 2;
+    const bool xin = jin && gk >= 1 && gk <= nK - 2, yin = jin && gk + 1 >= 1 && gk + 1 <= nK - 2;
+    // red phase: the block plus one ring = rows 1..14, columns 1..30 of the region
+    const bool xr = xin && lj >= 1 && lj <= BJ - 2 && lkp >= 1, yr = yin && lj >= 1 && lj <= BJ - 2 && lkp <= H - 2;
+    // black phase: the block = rows 2..13, columns 2..29
+    const bool own = lj >= 2 && lj <= BJ - 3 && lkp >= 1 && lkp <= H - 2;
+    const bool xb = xin && own, yb = yin && own;
+
+    double *X = su + 1, *Y = su + ELEM + 1;   // element images; the guard words take the reads off either end
+    const int at = lj * H + lkp;
+#pragma unroll
+    for (int q = 0; q < BI; q++) {
+        X[q * PLANE + at] = v[q].x;
+        Y[q * PLANE + at] = v[q].y;
+    }
+    __syncthreads();
+    // offsets of the row above / below, clamped for the threads of the first and last row (they
+    // update nothing; the clamp keeps their reads inside the image)
+    const int up = lj > 0 ? -H : 0, dn = lj < BJ - 1 ? H : 0;
+
+    // One colour of the planes [QA, QB): the element of plane q's pair whose global colour is
+    // `colour`, where xok / yok allows it.  publish: the new value also goes to the image.
+    auto phase = [&](auto qa_, auto qb_, int colour, bool xok, bool yok, bool publish) {
+        constexpr int QA = decltype(qa_)::value, QB = decltype(qb_)::value, N = QB - QA;
+        double x[N], g[N];
+        int e[N];
+#pragma unroll
+        for (int t = 0; t < N; t++) {
+            const int q = QA + t;
+            e[t] = (gi0 + q + gj + colour) & 1;                  // 1: the odd element has this colour
+            const double *E = (e[t] ? Y : X) + q * PLANE + at;   // this element's image: j neighbours
+            const double *F = (e[t] ? X : Y) + q * PLANE + at;   // the other element's: the far k neighbour
+            const double mate = pick(v[q], 1 - e[t]);
+            const double far = e[t] ? F[1] : F[-1];
+            const double kz = e[t] ? mate + far : far + mate;    // u[k-1] + u[k+1]
+            x[t] = pick(rb[q], e[t]) + c.cx * (pick(v[q - 1], e[t]) + pick(v[q + 1], e[t])) + c.cy * (E[up] + E[dn]) +
+                   c.cz * kz;
+        }
+        div_d_n<N>(x, c, g);
+#pragma unroll
+        for (int t = 0; t < N; t++) {
+            const int q = QA + t;
+            const int gi = gi0 + q;
+            const bool ok = (e[t] ? yok : xok) && gi >= 1 && gi <= nI - 2;
+            const double u0 = pick(v[q], e[t]);
+            const double un = ok ? u0 + omega * (g[t] - u0) : u0;
+            if (e[t]) v[q].y = un;
+            else v[q].x = un;
+            if (publish) (e[t] ? Y : X)[q * PLANE + at] = un;
+        }
+    };
+    phase(std::integral_constant<int, 1>{}, std::integral_constant<int, BI - 1>{}, 0, xr, yr, true);
+    __syncthreads();
+    phase(std::integral_constant<int, 2>{}, std::integral_constant<int, BI - 2>{}, 1, xb, yb, false);
+
+    if (own && gj < uJ && gk < uK) {
+        double *o = uout.p + (int64_t)gj * uout.sj + gk;
+#pragma unroll
+        for (int q = 2; q < BI - 2; q++) {
+            const int gi = gi0 + q;
+            if (gi < own_hi) *reinterpret_cast<d2 *>(o + (int64_t)(gi - (int)uout.i0) * uout.si) = v[q];
+        }
+    }
+}
+
+template <int TI>
+void launch_tile(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c, double omega, IRange r,
+                 IRange r2)
+{
+    const int tiles_j = (int)((uin.d[1] + kTileJ - 1) / kTileJ), tiles_k = (int)((uin.d[2] + kTileK - 1) / kTileK);
+    const int tiles_i1 = (int)((r.hi - r.lo + TI - 1) / TI);
+    const int tiles_i2 = r2.hi > r2.lo ? (int)((r2.hi - r2.lo + TI - 1) / TI) : 0;
+    const unsigned grid = (unsigned)(tiles_j * tiles_k) * (unsigned)(tiles_i1 + tiles_i2);
+    hipLaunchKernelGGL((k_sweep_tile<TI>), dim3(grid), dim3(256), 0, s, uin, uout, rhs, (int)n[0], (int)n[1], (int)n[2], c,
+                       omega, tiles_j, tiles_k, tiles_i1, (int)r.lo, (int)r.hi, (int)r2.lo, (int)r2.hi);
+}
+
+}  // namespace
+
+// One full red-black sweep of planes r (and r2) of u_in into u_out by 3-D tiles.  u_in must hold
+// planes [r.lo-2, r.hi+2) as far as they exist in the level, rhs planes [r.lo-1, r.hi+1).
+void sweep_rb_tile(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c, double omega, IRange r,
+                   IRange r2)
+{
+    if (r.hi <= r.lo) return;
+    static const int shape = exp_knob("MG_EXP_TILE", 0);
+    const int64_t planes = r.hi - r.lo;
+    // planes per tile: few for short ranges and small levels (more workgroups), more for large
+    // planes (each tile re-reads four planes of halo)
+    // (measured per sweep, 34^3: 3.8 / 4.4 / 5.5 us with 2 / 4 / 8 planes per tile; 66^3: 7.3 - 7.5 us alike)
+    int ti = planes <= 2 ? 2 : (planes <= 4 || uin.d[1] * uin.d[2] <= 80 * 80) ? 4 : 8;
+    if (shape) ti = shape;
+    if (ti == 2) launch_tile<2>(s, uin, uout, rhs, n, c, omega, r, r2);
+    else if (ti == 4) launch_tile<4>(s, uin, uout, rhs, n, c, omega, r, r2);
+    else if (ti == 12) launch_tile<12>(s, uin, uout, rhs, n, c, omega, r, r2);
+    else launch_tile<8>(s, uin, uout, rhs, n, c, omega, r, r2);
+}
+
+}  // namespace mgk

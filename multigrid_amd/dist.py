@@ -17,8 +17,9 @@ bit-identical to the undivided red-black cycle:
     then the interior -- which needs no halo plane of the previous sweep either -- so the
     exchange runs under the interior sweep; the fine residual is split the same way;
   * the sum of squared residuals is all-reduced once per cycle;
-  * level `cut` and everything below it is gathered onto rank 0, solved there on
-    whole arrays, and eps_cut is scattered back.
+  * R of level `cut` is all-gathered and every rank solves level `cut` and everything below it
+    on whole arrays of its own (those levels are serial work of the cycle whoever runs them);
+    eps_cut then needs no transfer: each rank prolongs from its own copy.
 
 The orchestration below is backend-agnostic: `ops` runs one operator on local slabs
 (HipOps: the mg_dev_* entry points of libmg_hip on device tensors).  There is no CPU
@@ -60,24 +61,11 @@ class SlabPlan:
         self.bounds = [0] * W + [self.n0[0]]  # fine-plane boundaries
         if W == 1:
             return
-        # Rank 0 also runs the gathered levels cut..L while the others wait: it owns fewer units when
-        # that shortens the slowest rank's cycle (the same estimate as Plan::init in
-        # csrc/mg_dist.hip; it only shifts work between ranks, never the result).
-        t_unit = float(align) * float(self.n0[1]) * float(self.n0[2]) * 17e-12
-        t_tail = 60e-6 * (L - cut + 1) + 20e-6
-        relief, best = 0, float(even) * t_unit + t_tail
-        for r in range(1, even // 4 + 1):
-            rest = units - (even - r)
-            most = (rest + W - 2) // (W - 1)
-            cost = max(float(even - r) * t_unit + t_tail, float(most) * t_unit)
-            if cost < best * (1 - 1e-9):
-                best, relief = cost, r
-        first = even - relief
-        rest = units - first
-        each, spare = divmod(rest, W - 1)
-        self.bounds[1] = first * align
-        for r in range(2, W):
-            self.bounds[r] = self.bounds[r - 1] + (each + (1 if r - 1 <= spare else 0)) * align
+        # whole units as evenly as they go, the spare ones to the lower ranks (as Plan::init in
+        # csrc/mg_dist.hip)
+        spare = units % W
+        for r in range(1, W):
+            self.bounds[r] = self.bounds[r - 1] + (even + (1 if r - 1 < spare else 0)) * align
 
     def level_n(self, l):
         return tuple(a >> l for a in self.n0)
@@ -329,32 +317,18 @@ class Comm:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def gather_planes(self, plan, l, kind, slab, full):
-        """Owned planes of every rank -> rank 0's whole array `full`."""
+    def allgather_planes(self, plan, l, kind, slab, full):
+        """Owned planes of every rank -> every rank's whole array `full`."""
+        lo, hi = plan.own(l, kind, self.rank)
+        full.rows(lo, hi).copy_(slab.rows(lo, hi))
         ops = []
-        if self.rank == 0:
-            lo, hi = plan.own(l, kind, 0)
-            full.rows(lo, hi).copy_(slab.rows(lo, hi))
-            for r in range(1, self.world):
-                lo, hi = plan.own(l, kind, r)
-                ops.append(dist.P2POp(dist.irecv, full.rows(lo, hi), r, self.group))
-        else:
-            lo, hi = plan.own(l, kind, self.rank)
-            ops.append(dist.P2POp(dist.isend, slab.rows(lo, hi), 0, self.group))
-        self._run(ops)
-
-    def scatter_planes(self, plan, l, kind, full, slab, halo):
-        """Rank 0's whole array -> every rank's stored planes (owned + halo)."""
-        ops = []
-        if self.rank == 0:
-            lo, hi = plan.stored(l, kind, 0, halo)
-            slab.rows(lo, hi).copy_(full.rows(lo, hi))
-            for r in range(1, self.world):
-                lo, hi = plan.stored(l, kind, r, halo)
-                ops.append(dist.P2POp(dist.isend, full.rows(lo, hi), r, self.group))
-        else:
-            lo, hi = plan.stored(l, kind, self.rank, halo)
-            ops.append(dist.P2POp(dist.irecv, slab.rows(lo, hi), 0, self.group))
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            olo, ohi = plan.own(l, kind, r)
+            ops.append(dist.P2POp(dist.isend, slab.rows(lo, hi), r, self.group))
+            ops.append(dist.P2POp(dist.irecv, full.rows(olo, ohi), r, self.group))
+        self.bytes_sent += sum(o.tensor.numel() * 8 for o in ops if o.op is dist.isend)
         self._run(ops)
 
 
@@ -401,11 +375,10 @@ class DistSolver:
         self.R = {l: slab(l, "R", self.H_RHS) for l in range(1, self.cut + 1)}
         self.eps = {l: slab(l, "eps", self.H_U) for l in range(1, self.cut + 1)}
         self.eps_alt = {l: slab(l, "eps", self.H_U) for l in range(1, self.cut)}
-        # gathered levels cut..depth, whole arrays, rank 0 only
+        # levels cut..depth: whole arrays on every rank
         self.cR, self.ceps, self.ceps_alt = {}, {}, {}
-        if r == 0:
-            for l in range(self.cut, depth + 1):
-                self.cR[l], self.ceps[l], self.ceps_alt[l] = whole(l, "R"), whole(l, "eps"), whole(l, "eps")
+        for l in range(self.cut, depth + 1):
+            self.cR[l], self.ceps[l], self.ceps_alt[l] = whole(l, "R"), whole(l, "eps"), whole(l, "eps")
         self.n_nodes = float(self.plan.n0[0]) * self.plan.n0[1] * self.plan.n0[2]
         self.last_sum = None
         self.correction_pending = False
@@ -547,8 +520,8 @@ class DistSolver:
         return self.last_sum
 
     def coarse_correction(self):
-        """Steps 3)-5): restrict down to the cut level, gather, solve the small levels on rank 0,
-        scatter, then (prolong, smooth) up.  Step 6), the correction of phi, is left pending for the
+        """Steps 3)-5): restrict down to the cut level, all-gather it, solve the small levels (every
+        rank), then (prolong, smooth) up.  Step 6), the correction of phi, is left pending for the
         next iteration's first sweep (flush_correction() applies it when no iteration follows)."""
         P, ops, comm = self.plan, self.ops, self.comm
         for l in range(1, self.cut):
@@ -556,10 +529,11 @@ class DistSolver:
             comm.exchange(self.R[l], self.own(l, "R"), self.H_RHS)
             lo, hi = self.own(l + 1, "R")
             ops.restrict27(self.R[l], self.R[l + 1], P.level_n(l), lo, hi)
-        comm.gather_planes(P, self.cut, "R", self.R[self.cut], self.cR.get(self.cut))
-        if self.rank == 0:
-            self._coarse_levels()
-        comm.scatter_planes(P, self.cut, "eps", self.ceps.get(self.cut), self.eps[self.cut], self.H_U)
+        comm.allgather_planes(P, self.cut, "R", self.R[self.cut], self.cR[self.cut])
+        self._coarse_levels()
+        # eps_cut on this rank's stored planes: a local copy out of its own whole array
+        lo, hi = P.stored(self.cut, "eps", self.rank, self.H_U)
+        self.eps[self.cut].rows(lo, hi).copy_(self.ceps[self.cut].rows(lo, hi))
         for l in range(self.cut - 1, 0, -1):
             if self.nu[l] > 0:
                 # eps_l = P(eps_{l+1}) as the first sweep's input, on halo planes too (eps_{l+1}'s
@@ -573,7 +547,7 @@ class DistSolver:
         self.correction_pending = True
 
     def _coarse_levels(self):
-        """Levels cut..depth on whole arrays (rank 0): restrict down, smooth the coarsest,
+        """Levels cut..depth on whole arrays (every rank its own): restrict down, smooth the coarsest,
         (prolong, smooth) back up to level `cut`."""
         P, ops, L = self.plan, self.ops, self.depth
         for l in range(self.cut, L):

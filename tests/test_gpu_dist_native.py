@@ -207,7 +207,7 @@ def test_a_rank_alone_runs_its_share_of_a_larger_world(gpu):
     dh = problem.main_extents_dh(N)
     from multigrid_amd.dist import SlabPlan
     plan = SlabPlan(N, depth, 4, cut=2)  # the Python twin's arithmetic: both drivers cut the grid alike
-    assert plan.bounds[1] < plan.bounds[2] - plan.bounds[1]  # rank 0 owns less: it also runs the gathered levels
+    assert plan.bounds[1] == plan.bounds[2] - plan.bounds[1]  # equal shares: every rank runs the whole levels too
     for rank in (1, 0):
         d = gpu.DistRank(N, dh, depth, rank, 4, device=0, coarse_cut=2, alone=True)
         try:

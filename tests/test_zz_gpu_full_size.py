@@ -58,9 +58,9 @@ def test_slab_plans_of_the_scaling_run_equal_the_undivided_grid_at_1025(gpu, und
         for i, s in enumerate(sums):
             got[lo + i] = s
         assert h == pytest.approx(hist, rel=1e-12) and h == res[0][4]
-    # the plan of the strong-scaling run: whole units of 2^cut planes, rank 0 relieved of some
+    # the plan of the strong-scaling run: equal shares of whole units of 2^cut planes
     sizes = [own[1] - own[0] for _, own, _, _, _ in res]
-    assert sum(sizes) == N1 and all(s % 8 == 0 for s in sizes[:-1]) and sizes[0] <= sizes[1]
+    assert sum(sizes) == N1 and all(s == (N1 - 1) // world for s in sizes[:-1]) and sizes[-1] == sizes[0] + 1
     assert all(g is not None for g in got)
     bad = [i for i in range(N1) if got[i] != want[i]]
     assert not bad, f"planes that differ between the partitioned and the undivided solve: {bad[:8]} ..."

@@ -2,7 +2,7 @@
 """GPU time of ONE rank's share of the slab-partitioned V-cycle, measured on one GPU without peers.
 
 The rank runs the schedule it would run in a world of W ranks (same slab, same edge / interior
-launches, the coarse tail on rank 0) with a communicator that moves nothing: halo planes keep
+launches, the whole coarse levels) with a communicator that moves nothing: halo planes keep
 their initial zeros, so the numbers mean nothing, the kernels and their launch geometry are the
 real ones.  What is missing from these times is only what the transport adds on a multi-GPU node.
 
@@ -24,7 +24,7 @@ from multigrid_amd import dist as mgd, problem  # noqa: E402
 
 
 class SoloComm(mgd.Comm):
-    """Rank `rank` of `world`, alone: every transfer is skipped, gather/scatter keep rank 0's own part."""
+    """Rank `rank` of `world`, alone: every transfer is skipped, the all-gather keeps the rank's own part."""
 
     def __init__(self, rank, world):
         super().__init__()
@@ -39,15 +39,9 @@ class SoloComm(mgd.Comm):
     def allreduce_sum(self, t):
         return t
 
-    def gather_planes(self, plan, l, kind, slab, full):
-        if self.rank == 0:
-            lo, hi = plan.own(l, kind, 0)
-            full.rows(lo, hi).copy_(slab.rows(lo, hi))
-
-    def scatter_planes(self, plan, l, kind, full, slab, halo):
-        if self.rank == 0:
-            lo, hi = plan.stored(l, kind, 0, halo)
-            slab.rows(lo, hi).copy_(full.rows(lo, hi))
+    def allgather_planes(self, plan, l, kind, slab, full):
+        lo, hi = plan.own(l, kind, self.rank)
+        full.rows(lo, hi).copy_(slab.rows(lo, hi))
 
 
 def measure(n, world, rank, cycles=10, overlap=True, cut=None):

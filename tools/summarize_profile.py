@@ -69,15 +69,21 @@ def main(tag):
             n32, n64, n128 = (best.get(f"TCC_EA0_RDREQ_{w}B_sum", 0.0) for w in (32, 64, 128))
             kern[k]["read_requests_max_launch"] = {"32B": n32, "64B": n64, "128B": n128,
                                                    "bytes": 32 * n32 + 64 * n64 + 128 * n128}
-    bench = json.load(open(os.path.join(src, "bench_stats.json")))
-    out = {"tag": tag, "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 "
-                                  "--cpu-cycles 0 --no-solve (513^3 V5); --pmc FETCH_SIZE / --pmc WRITE_SIZE in "
-                                  "separate runs with --steps 3",
-           "bench_under_profiler": {k: bench[k] for k in ("value", "ms_per_step", "roofline")},
-           "kernels": kern}
+    # the same key per grid size where a kernel runs on several shapes (slab runs: edge and interior launches)
+    out = {"tag": tag, "kernels": kern}
+    if os.path.exists(os.path.join(src, "command.txt")):   # tools/profile_slab.sh
+        out["command"] = open(os.path.join(src, "command.txt")).read().strip()
+        title = "one rank of the slab-partitioned 1025^3 V6 cycle, one MI355X"
+    else:
+        bench = json.load(open(os.path.join(src, "bench_stats.json")))
+        out["command"] = ("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 "
+                          "--cpu-cycles 0 --no-solve (513^3 V5); --pmc FETCH_SIZE / --pmc WRITE_SIZE in "
+                          "separate runs with --steps 3")
+        out["bench_under_profiler"] = {k: bench[k] for k in ("value", "ms_per_step", "roofline")}
+        title = "513^3 V5 cycle, one MI355X"
     json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
     with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
-        f.write(f"# rocprofv3 summary `{tag}` — 513^3 V5 cycle, one MI355X\n\n{out['command']}\n\n")
+        f.write(f"# rocprofv3 summary `{tag}` — {title}\n\n{out['command']}\n\n")
         f.write("| kernel | calls | avg us | max us | % time | FETCH_SIZE max (MB) | WRITE_SIZE max (MB) | "
                 "HBM bytes/launch = 2 x FETCH + WRITE (MB) | read bytes from request sizes (MB) |\n|---|---|---|---|---|---|---|---|---|\n")
         for k, d in sorted(kern.items(), key=lambda kv: -kv[1]["pct"]):
