@@ -64,7 +64,7 @@ typedef struct mg_handle mg_handle;
  *           library (halo planes over RCCL send/recv; when an ordinal repeats in devices[], over
  *           device-to-device copies, which lets the partitioned path run on one GPU).  Such a
  *           handle serves mg_set_rho / mg_set_phi / mg_solve / mg_vcycle(s) / mg_get_phi /
- *           mg_last_call_ms / mg_destroy; depth >= 1, flags == 0.
+ *           mg_last_call_ms / mg_destroy; depth >= 1, flags 0 or MG_FLAG_FAST_SMOOTHER.
  *   coarse_cut  first level that is not partitioned: every GPU holds it and the coarser ones whole
  *           and solves them itself (0 = the first one with <= 128 planes) */
 typedef struct mg_config {
@@ -95,6 +95,20 @@ typedef struct mg_config {
  * first mg_compute_ef, for callers that follow every solve with computeEF() (cpp/Main.cpp:124-126,
  * :157-166) and time or capture that call.  Single-GPU handles. */
 #define MG_FLAG_RESERVE_EF 4
+/* Coarse-level smoothers in their short form.  By default a point update evaluates the reference's
+ * expression in the reference's order (cpp/PotentialSolver.cpp:3929-3935: three products, a sum, a
+ * correctly rounded division by the stencil diagonal, then e + omega*(g - e)) so that the
+ * red-black iterates can be compared bit for bit with a scalar CPU evaluation.  With this flag the
+ * sweeps on every level l >= 1 evaluate the same update as one chain of fused multiply-adds on
+ * coefficients that already carry the division and omega,
+ *   e = fma(wz, e[k-1]+e[k+1], fma(wy, e[j-1]+e[j+1], fma(wx, e[i-1]+e[i+1], fma(wb, R, (1-omega)*e))))
+ * with wb = omega*(1/d), wx = (omega*cx)*(1/d), ...: 8 floating-point operations instead of 22, on
+ * the levels whose sweeps are bound by instruction issue.  The fine-grid sweep (bound by memory,
+ * where the short form does not pay), residual, restriction, prolongation and the norm are
+ * unaffected and stay exact, so a solve still stops on an exactly evaluated residual; the two
+ * forms differ by rounding (a few ulp per update).  Handles of any kind (also n_gpus > 1); no
+ * effect on mg_gs_solve, which sweeps the fine grid. */
+#define MG_FLAG_FAST_SMOOTHER 8
 
 /* Accumulated device time per operator, measured with HIP events on the
  * handle's stream while profiling is on (mg_set_profiling).  Index with
@@ -395,7 +409,7 @@ int mg_dev_compute_ef(void *stream, const mg_dev_array *phi, void *ef, int64_t e
 typedef struct mg_dist mg_dist;
 typedef struct mg_local_group mg_local_group;
 typedef struct mg_dist_config {
-    mg_config base;      /* the GLOBAL grid (n, dh, depth, nu, omega); device = this rank's GPU; flags 0 */
+    mg_config base;      /* the GLOBAL grid (n, dh, depth, nu, omega); device = this rank's GPU; flags 0 or MG_FLAG_FAST_SMOOTHER */
     int32_t rank, world;
     int32_t coarse_cut;  /* levels >= this are held and solved whole by every rank; 0 = first level with <= 128 planes */
     int32_t transport;   /* MG_TRANSPORT_* */

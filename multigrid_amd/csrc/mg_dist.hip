@@ -970,7 +970,8 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
     if (cfg->world < 1 || cfg->world > MG_MAX_GPUS || cfg->rank < 0 || cfg->rank >= cfg->world)
         FAIL(MG_ERR_INVALID, "rank %d / world %d out of range", cfg->rank, cfg->world);
     if (base.depth < 1 || base.depth >= MG_MAX_LEVELS) FAIL(MG_ERR_INVALID, "depth %d out of range 1..%d", base.depth, MG_MAX_LEVELS - 1);
-    if (base.flags) FAIL(MG_ERR_INVALID, "a partitioned solve supports no MG_FLAG_* options");
+    if (base.flags & ~MG_FLAG_FAST_SMOOTHER)
+        FAIL(MG_ERR_INVALID, "a partitioned solve supports no MG_FLAG_* option but MG_FLAG_FAST_SMOOTHER");
     for (int a = 0; a < 3; a++) {
         if (base.n[a] < 3 || base.n[a] > 65535) FAIL(MG_ERR_INVALID, "n[%d]=%lld out of range", a, (long long)base.n[a]);
         if (!(base.dh[a] > 0)) FAIL(MG_ERR_INVALID, "dh[%d] must be positive", a);
@@ -1016,6 +1017,7 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
         double k[4];
         CREATE_TRY(mg_level_coef(base.dh, l, k));
         d->c[l] = mgk::make_coef(k[0], k[1], k[2], k[3]);
+        if ((base.flags & MG_FLAG_FAST_SMOOTHER) && l >= 1) d->c[l] = mgk::with_fast_smoother(d->c[l], base.omega);
     }
     CREATE_TRY(hip_ok(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), "hipStreamCreate"));
     CREATE_TRY(hip_ok(hipEventCreate(&d->ev_a), "hipEventCreate"));

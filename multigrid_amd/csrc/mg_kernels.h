@@ -83,9 +83,15 @@ struct Coef {
     double cx, cy, cz, d;
     double rd;     // 1.0/d, correctly rounded
     int fma_div;   // 1: div_d() may use the reciprocal form (see div_d)
+    // The smoother's update with the division and omega folded into the coefficients
+    // (MG_FLAG_FAST_SMOOTHER; see sor_n): fb = omega*rd, fx = (omega*cx)*rd, fy, fz alike, fu = 1 - omega.
+    int fast;
+    double fb, fx, fy, fz, fu;
 };
 // Fills rd / fma_div from d.
 Coef make_coef(double cx, double cy, double cz, double d);
+// c with the folded coefficients of sor_n<true> for this omega, and fast = 1.
+Coef with_fast_smoother(Coef c, double omega);
 // on: coefficients made from now on divide with the division instruction (fma_div = 0).
 void set_exact_division(bool on);
 
@@ -130,6 +136,35 @@ __device__ __forceinline__ void div_d_n(const double (&x)[N], const Coef &c, dou
 #pragma unroll
         for (int n = 0; n < N; n++)
             if (!c.fma_div || ((uint32_t)__double2hiint(x[n]) & 0x7fffffffu) - kLo >= kSpan) g[n] = x[n] / c.d;
+    }
+}
+
+// The SOR update of N points: b = right-hand side, si / sj / sk = u[i-1]+u[i+1], u[j-1]+u[j+1],
+// u[k-1]+u[k+1] (each summed in that order), u0 = the current value.
+//   FAST = false: the reference's expression in its order (cpp/PotentialSolver.cpp:3780-3786, :3929-3935),
+//       g = (((b + cx*si) + cy*sj) + cz*sk) / d;  u = u0 + omega*(g - u0)
+//     bit-identical to the scalar CPU evaluation (17 operations and a correctly rounded quotient);
+//   FAST = true: the same update as one chain of fused multiply-adds on coefficients that carry
+//     the division and omega,
+//       u = fma(fz, sk, fma(fy, sj, fma(fx, si, fma(fb, b, fu*u0))))
+//     8 operations; equal to the other form up to rounding (a few ulp per update), which the
+//     smoother of an iteration that measures its residual exactly can afford.
+template <bool FAST, int N>
+__device__ __forceinline__ void sor_n(const double (&b)[N], const double (&si)[N], const double (&sj)[N],
+                                      const double (&sk)[N], const double (&u0)[N], const Coef &c, double omega,
+                                      double (&un)[N])
+{
+    if constexpr (FAST) {
+#pragma unroll
+        for (int n = 0; n < N; n++)
+            un[n] = fma(c.fz, sk[n], fma(c.fy, sj[n], fma(c.fx, si[n], fma(c.fb, b[n], c.fu * u0[n]))));
+    } else {
+        double x[N], g[N];
+#pragma unroll
+        for (int n = 0; n < N; n++) x[n] = b[n] + c.cx * si[n] + c.cy * sj[n] + c.cz * sk[n];
+        div_d_n<N>(x, c, g);
+#pragma unroll
+        for (int n = 0; n < N; n++) un[n] = u0[n] + omega * (g[n] - u0[n]);
     }
 }
 

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void k_repitch_out(double *__restrict__ dense,
 // One colour of GS-SOR.  u_new = u + omega*(g - u),
 // g = (((b + cx*(u[i-1]+u[i+1])) + cy*(u[j-1]+u[j+1])) + cz*(u[k-1]+u[k+1])) / d
 // (reference cpp/PotentialSolver.cpp:3780-3786 and :3929-3935).
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_smooth_colour(View u, View rhs, int64_t nj, int64_t nk,
                                                        Coef c, double omega, int colour, int64_t ilo)
 {
@@ -63,11 +64,11 @@ __global__ __launch_bounds__(256) void k_smooth_colour(View u, View rhs, int64_t
     const int64_t k = 1 + ((i + j + 1 + colour) & 1) + 2 * m;
     if (j > nj - 2 || k > nk - 2) return;
     double *p = u.p + u.at(i, j, k);
-    const double b = rhs.p[rhs.at(i, j, k)];
-    const double g = div_d(b + c.cx * (p[-u.si] + p[u.si]) + c.cy * (p[-u.sj] + p[u.sj]) +
-                           c.cz * (p[-1] + p[1]), c);
-    const double u0 = p[0];
-    p[0] = u0 + omega * (g - u0);
+    const double b[1] = {rhs.p[rhs.at(i, j, k)]}, si[1] = {p[-u.si] + p[u.si]}, sj[1] = {p[-u.sj] + p[u.sj]},
+                 sk[1] = {p[-1] + p[1]}, u0[1] = {p[0]};
+    double un[1];
+    sor_n<FAST, 1>(b, si, sj, sk, u0, c, omega, un);
+    p[0] = un[0];
 }
 
 // All sweeps of a small level inside one workgroup: u lives in LDS, the two colours are
@@ -86,7 +87,7 @@ __host__ __device__ inline size_t smooth_lds_doubles(int64_t uI, int64_t uJ, int
     return (size_t)(2 * uI * uJ * ((uK + 1) / 2));
 }
 
-template <int P, int NT = 1024>
+template <int P, int NT = 1024, bool FAST = false>
 __global__ __launch_bounds__(NT) void k_smooth_lds(View u, View rhs, int nI, int nJ, int nK,
                                                    Coef c, double omega, int sweeps)
 {
@@ -131,21 +132,20 @@ __global__ __launch_bounds__(NT) void k_smooth_lds(View u, View rhs, int nI, int
     for (int s = 0; s < sweeps; s++) {
 #pragma unroll
         for (int colour = 0; colour < 2; colour++) {
-            double x[P], g[P];
+            double ti[P], tj[P], tk[P], un[P];
 #pragma unroll
             for (int q = 0; q < P; q++) {
                 // a thread without a point reads around some interior entry and discards the result
                 const int o = off[colour][q] < 0 ? (1 - colour) * HALF + si + sj + 1 : off[colour][q];
                 const double *p = su + o;
                 const double *pk = p + kodd[colour][q];
-                x[q] = b[colour][q] + c.cx * (p[-si] + p[si]) + c.cy * (p[-sj] + p[sj]) + c.cz * (pk[-1] + pk[0]);
+                ti[q] = p[-si] + p[si];
+                tj[q] = p[-sj] + p[sj];
+                tk[q] = pk[-1] + pk[0];
             }
-            div_d_n<P>(x, c, g);  // the quotients of a thread's points behind one branch
+            sor_n<FAST, P>(b[colour], ti, tj, tk, cur[colour], c, omega, un);  // the quotients of a thread's points behind one branch
 #pragma unroll
-            for (int q = 0; q < P; q++) {
-                const double u0 = cur[colour][q];
-                cur[colour][q] = u0 + omega * (g[q] - u0);
-            }
+            for (int q = 0; q < P; q++) cur[colour][q] = un[q];
 #pragma unroll
             for (int q = 0; q < P; q++)  // own entry: same (i, j, k>>1), this colour's half
                 if (off[colour][q] >= 0) su[off[colour][q] + (colour ? HALF : -HALF)] = cur[colour][q];
@@ -341,6 +341,8 @@ Coef make_coef(double cx, double cy, double cz, double d)
     c.cz = cz;
     c.d = d;
     c.rd = 1.0 / d;
+    c.fast = 0;
+    c.fb = c.fx = c.fy = c.fz = c.fu = 0.0;
     // the reciprocal form needs a positive d within 2^-100..2^100 (any real mesh coefficient)
     // whose significand is not all ones; div_d() bounds the numerator
     uint64_t bits;
@@ -367,6 +369,17 @@ int64_t pitch_for(int64_t nk)
     }
     if (mode > 1 && nk >= 192) return ((nk + 1) & ~int64_t(1)) + mode;
     return (nk + 1) & ~int64_t(1);
+}
+
+Coef with_fast_smoother(Coef c, double omega)
+{
+    c.fast = 1;
+    c.fb = omega * c.rd;
+    c.fx = (omega * c.cx) * c.rd;
+    c.fy = (omega * c.cy) * c.rd;
+    c.fz = (omega * c.cz) * c.rd;
+    c.fu = 1.0 - omega;
+    return c;
 }
 
 namespace {
@@ -414,8 +427,12 @@ void smooth_colour(hipStream_t s, View u, View rhs, const int64_t n[3], Coef c, 
     const int64_t lo = r.lo < 1 ? 1 : r.lo, hi = r.hi > n[0] - 1 ? n[0] - 1 : r.hi;
     if (hi <= lo) return;
     const int64_t half = (n[2] - 2 + 1) / 2;  // k positions of one colour in a row, at most
-    hipLaunchKernelGGL(k_smooth_colour, grid_for(half, n[1] - 2, hi - lo), dim3(kBX, kBY), 0, s, u, rhs,
-                       n[1], n[2], c, omega, colour, lo);
+    if (c.fast)
+        hipLaunchKernelGGL(k_smooth_colour<true>, grid_for(half, n[1] - 2, hi - lo), dim3(kBX, kBY), 0, s, u, rhs,
+                           n[1], n[2], c, omega, colour, lo);
+    else
+        hipLaunchKernelGGL(k_smooth_colour<false>, grid_for(half, n[1] - 2, hi - lo), dim3(kBX, kBY), 0, s, u, rhs,
+                           n[1], n[2], c, omega, colour, lo);
 }
 
 // Kernel choice for the smoother: the fused single-pass sweep pays once the level
@@ -455,8 +472,9 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
     const int64_t per_colour = (n[0] - 2) * (n[1] - 2) * ((n[2] - 1) / 2);
     static const bool lds_ok = [] {
         bool ok = true;
-        for (const void *f : {(const void *)k_smooth_lds<2, 256>, (const void *)k_smooth_lds<2, 1024>,
-                              (const void *)k_smooth_lds<4, 1024>})
+        for (const void *f : {(const void *)k_smooth_lds<2, 256, false>, (const void *)k_smooth_lds<2, 1024, false>,
+                              (const void *)k_smooth_lds<4, 1024, false>, (const void *)k_smooth_lds<2, 256, true>,
+                              (const void *)k_smooth_lds<2, 1024, true>, (const void *)k_smooth_lds<4, 1024, true>})
             ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsSmoothMaxBytes) == hipSuccess;
         return ok;
     }();
@@ -464,15 +482,19 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
         // Thread count by measurement (50 sweeps; 256 / 512 / 1024 threads): 365 points per colour
         // 31 / 37 / 53 us, 1372 points 98 / 74 / 68 us, 2916 points - / 148 / 125 us.  The phases of a
         // tiny level are latency (fewer waves meet at the barriers), those of a larger one throughput.
-        if (per_colour <= 2 * 256)
-            hipLaunchKernelGGL((k_smooth_lds<2, 256>), dim3(1), dim3(256), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
-                               (int)n[2], c, omega, sweeps);
-        else if (per_colour <= 2 * 1024)
-            hipLaunchKernelGGL((k_smooth_lds<2, 1024>), dim3(1), dim3(1024), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
-                               (int)n[2], c, omega, sweeps);
-        else
-            hipLaunchKernelGGL((k_smooth_lds<4, 1024>), dim3(1), dim3(1024), lds_bytes, s, *u, rhs, (int)n[0], (int)n[1],
-                               (int)n[2], c, omega, sweeps);
+#define LDS_LAUNCH(P, NT)                                                                                             \
+    do {                                                                                                              \
+        if (c.fast)                                                                                                   \
+            hipLaunchKernelGGL((k_smooth_lds<P, NT, true>), dim3(1), dim3(NT), lds_bytes, s, *u, rhs, (int)n[0],      \
+                               (int)n[1], (int)n[2], c, omega, sweeps);                                               \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_smooth_lds<P, NT, false>), dim3(1), dim3(NT), lds_bytes, s, *u, rhs, (int)n[0],     \
+                               (int)n[1], (int)n[2], c, omega, sweeps);                                               \
+    } while (0)
+        if (per_colour <= 2 * 256) LDS_LAUNCH(2, 256);
+        else if (per_colour <= 2 * 1024) LDS_LAUNCH(2, 1024);
+        else LDS_LAUNCH(4, 1024);
+#undef LDS_LAUNCH
         return 1;
     }
     const bool tile = alt && alt->p && use_tile_sweep() && (!use_fused_sweep(*u) || r.hi - r.lo <= tile_max_planes());

@@ -87,34 +87,54 @@ __device__ __forceinline__ double lane_right(double v)
 // lane's first one, so every access is P plus a non-negative constant; vc is the plane being
 // updated, va / vb its i-1 / i+1 neighbours, all as the lane's registers hold them.
 // okmask: bit E * Q + q = the point may be updated.  PUBLISH: new values also go to the slot.
-template <int E, int Q, int ROWSTEP, int WKP, int HALF, bool PUBLISH>
+template <int E, int Q, int ROWSTEP, int WKP, int HALF, bool PUBLISH, bool FAST>
 __device__ __forceinline__ void phase_split(double *P, d2 (&vc)[Q], const d2 (&va)[Q], const d2 (&vb)[Q],
                                             const d2 (&b)[Q], unsigned okmask, const Coef &c, double omega)
 {
-    double x[Q], g[Q];
+    // (the two forms of the update -- see sor_n -- are spelled out here: the sums go straight into
+    // the expression, which keeps a lane's four rows within the register budget)
+    if constexpr (FAST) {
 #pragma unroll
-    for (int q = 0; q < Q; q++) {
-        const double *X = P + E * HALF + q * ROWSTEP;
-        const double mate = elem<1 - E>(vc[q]);
-        const double far = E ? lane_right(mate) : lane_left(mate);
-        x[q] = elem<E>(b[q]) + c.cx * (elem<E>(va[q]) + elem<E>(vb[q])) + c.cy * (X[0] + X[2 * WKP]) +
-               c.cz * (E ? mate + far : far + mate);
-    }
-    div_d_n<Q>(x, c, g);
+        for (int q = 0; q < Q; q++) {
+            const double *X = P + E * HALF + q * ROWSTEP;
+            const double mate = elem<1 - E>(vc[q]);
+            const double far = E ? lane_right(mate) : lane_left(mate);
+            const double uc = elem<E>(vc[q]);
+            double t = fma(c.fb, elem<E>(b[q]), c.fu * uc);
+            t = fma(c.fx, elem<E>(va[q]) + elem<E>(vb[q]), t);
+            t = fma(c.fy, X[0] + X[2 * WKP], t);
+            t = fma(c.fz, E ? mate + far : far + mate, t);
+            const bool ok = (okmask >> (E * Q + q)) & 1u;
+            const double un = ok ? t : uc;
+            elem<E>(vc[q]) = un;
+            if (PUBLISH) P[E * HALF + q * ROWSTEP + WKP] = un;
+        }
+    } else {
+        double x[Q], g[Q];
 #pragma unroll
-    for (int q = 0; q < Q; q++) {
-        const double uc = elem<E>(vc[q]);
-        const bool ok = (okmask >> (E * Q + q)) & 1u;
-        const double un = ok ? uc + omega * (g[q] - uc) : uc;
-        elem<E>(vc[q]) = un;
-        if (PUBLISH) P[E * HALF + q * ROWSTEP + WKP] = un;
+        for (int q = 0; q < Q; q++) {
+            const double *X = P + E * HALF + q * ROWSTEP;
+            const double mate = elem<1 - E>(vc[q]);
+            const double far = E ? lane_right(mate) : lane_left(mate);
+            x[q] = elem<E>(b[q]) + c.cx * (elem<E>(va[q]) + elem<E>(vb[q])) + c.cy * (X[0] + X[2 * WKP]) +
+                   c.cz * (E ? mate + far : far + mate);
+        }
+        div_d_n<Q>(x, c, g);
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const double uc = elem<E>(vc[q]);
+            const bool ok = (okmask >> (E * Q + q)) & 1u;
+            const double un = ok ? uc + omega * (g[q] - uc) : uc;
+            elem<E>(vc[q]) = un;
+            if (PUBLISH) P[E * HALF + q * ROWSTEP + WKP] = un;
+        }
     }
 }
 
 // WJ rows x 2*WKP columns per window; outputs are the window minus two rings.
 // D = planes of u (and of the right-hand side) requested ahead of use: the march is
 // latency bound unless several planes per workgroup are in flight.
-template <int WJ, int WKP, int D, int NT, int MODE>
+template <int WJ, int WKP, int D, int NT, int MODE, bool FAST>
 __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, View ec, int nI, int nJ,
                                                   int nK, Coef c, double omega, int CI, int nchunks,
                                                   int tiles_k, int rlo, int rhi, WgOrder order, int cstride)
@@ -364,8 +384,8 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
         // of a wave take rows of equal parity: which element of a pair is red is wave-uniform.
         const bool e1 = __builtin_amdgcn_readfirstlane((p + j0 + rw) & 1) != 0;
         if (p >= 1 && p <= nI - 2) {
-            if (e1) phase_split<1, Q, RS, WKP, HALF, true>(slot(0), v0, vm1, vp1, b0, okmask, c, omega);
-            else phase_split<0, Q, RS, WKP, HALF, true>(slot(0), v0, vm1, vp1, b0, okmask, c, omega);
+            if (e1) phase_split<1, Q, RS, WKP, HALF, true, FAST>(slot(0), v0, vm1, vp1, b0, okmask, c, omega);
+            else phase_split<0, Q, RS, WKP, HALF, true, FAST>(slot(0), v0, vm1, vp1, b0, okmask, c, omega);
         }
         if (MODE != kLoadPlain && !(f & 1)) stage_write((f >> 1) + 1, cv);
         // No barrier between the phases: the black update of plane p-1 reads, from other lanes,
@@ -378,8 +398,8 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
         if (pb >= ia && pb < ib) {
             if (pb >= 1 && pb <= nI - 2) {
                 // black of plane p-1 sits where red of plane p does
-                if (e1) phase_split<1, Q, RS, WKP, HALF, false>(slot(1), vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
-                else phase_split<0, Q, RS, WKP, HALF, false>(slot(1), vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
+                if (e1) phase_split<1, Q, RS, WKP, HALF, false, FAST>(slot(1), vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
+                else phase_split<0, Q, RS, WKP, HALF, false, FAST>(slot(1), vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) {
@@ -422,7 +442,7 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
 // colour nobody reads in that phase: red positions of slot p, black of slot p-1 (read by sweep 2
 // an iteration later), red of slot p-2; the black update of plane p-3 goes to registers and out.
 // Outputs are the window minus four rings.
-template <int WJ, int WKP, int D, int NT>
+template <int WJ, int WKP, int D, int NT, bool FAST>
 __global__ __launch_bounds__(NT) void k_sweep_rb2(View uin, View uout, View rhs, int nI, int nJ, int nK,
                                                    Coef c, double omega, int CI, int nchunks, int tiles_k,
                                                    int rlo, int rhi, WgOrder order)
@@ -544,24 +564,24 @@ __global__ __launch_bounds__(NT) void k_sweep_rb2(View uin, View uout, View rhs,
         // same element is black in plane p-1, red in p-2, black in p-3
         const bool e1 = __builtin_amdgcn_readfirstlane((p + j0 + rw) & 1) != 0;
         if (p >= 1 && p <= nI - 2) {
-            if (e1) phase_split<1, Q, RS, WKP, HALF, true>(slot(0), v0, vm1, vp1, b0, okmask, c, omega);
-            else phase_split<0, Q, RS, WKP, HALF, true>(slot(0), v0, vm1, vp1, b0, okmask, c, omega);
+            if (e1) phase_split<1, Q, RS, WKP, HALF, true, FAST>(slot(0), v0, vm1, vp1, b0, okmask, c, omega);
+            else phase_split<0, Q, RS, WKP, HALF, true, FAST>(slot(0), v0, vm1, vp1, b0, okmask, c, omega);
         }
         const int pb = p - 1;
         if (pb >= p0 + 1 && pb >= 1 && pb <= nI - 2) {
-            if (e1) phase_split<1, Q, RS, WKP, HALF, true>(slot(1), vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
-            else phase_split<0, Q, RS, WKP, HALF, true>(slot(1), vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
+            if (e1) phase_split<1, Q, RS, WKP, HALF, true, FAST>(slot(1), vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
+            else phase_split<0, Q, RS, WKP, HALF, true, FAST>(slot(1), vm1, vm2, v0, bm1, okmask >> (2 * Q), c, omega);
         }
         const int pr = p - 2;
         if (pr >= p0 + 2 && pr >= 1 && pr <= nI - 2) {
-            if (e1) phase_split<1, Q, RS, WKP, HALF, true>(slot(2), vm2, vm3, vm1, bm2, okmask >> (4 * Q), c, omega);
-            else phase_split<0, Q, RS, WKP, HALF, true>(slot(2), vm2, vm3, vm1, bm2, okmask >> (4 * Q), c, omega);
+            if (e1) phase_split<1, Q, RS, WKP, HALF, true, FAST>(slot(2), vm2, vm3, vm1, bm2, okmask >> (4 * Q), c, omega);
+            else phase_split<0, Q, RS, WKP, HALF, true, FAST>(slot(2), vm2, vm3, vm1, bm2, okmask >> (4 * Q), c, omega);
         }
         const int pk = p - 3;
         if (pk >= ia) {
             if (pk >= 1 && pk <= nI - 2) {
-                if (e1) phase_split<1, Q, RS, WKP, HALF, false>(slot(3), vm3, vm4, vm2, bm3, okmask >> (6 * Q), c, omega);
-                else phase_split<0, Q, RS, WKP, HALF, false>(slot(3), vm3, vm4, vm2, bm3, okmask >> (6 * Q), c, omega);
+                if (e1) phase_split<1, Q, RS, WKP, HALF, false, FAST>(slot(3), vm3, vm4, vm2, bm3, okmask >> (6 * Q), c, omega);
+                else phase_split<0, Q, RS, WKP, HALF, false, FAST>(slot(3), vm3, vm4, vm2, bm3, okmask >> (6 * Q), c, omega);
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) {
@@ -615,8 +635,12 @@ static void launch_sweep2_t(hipStream_t s, View uin, View uout, View rhs, const 
     const int nchunks = pick_chunks(tiles, planes, 8, 1, 256, false);
     const int CI = (int)((planes + nchunks - 1) / nchunks);
     const WgOrder order{nchunks * tiles, 1};
-    hipLaunchKernelGGL((k_sweep_rb2<WJ, WKP, D, NT>), dim3(order.grid()), dim3(NT), 0, s, uin, uout, rhs, (int)n[0],
-                       (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k, (int)r.lo, (int)r.hi, order);
+    if (c.fast)
+        hipLaunchKernelGGL((k_sweep_rb2<WJ, WKP, D, NT, true>), dim3(order.grid()), dim3(NT), 0, s, uin, uout, rhs,
+                           (int)n[0], (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k, (int)r.lo, (int)r.hi, order);
+    else
+        hipLaunchKernelGGL((k_sweep_rb2<WJ, WKP, D, NT, false>), dim3(order.grid()), dim3(NT), 0, s, uin, uout, rhs,
+                           (int)n[0], (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k, (int)r.lo, (int)r.hi, order);
 }
 
 void sweep_rb_fused2(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c, double omega,
@@ -640,8 +664,6 @@ static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec
     const int tiles = tiles_j * tiles_k;
     const bool blocked = wg_order_blocked();
     int nchunks = pick_chunks(tiles, planes, 4, 1, WJ == 32 ? 512 : 256, !blocked);
-    static const int forced = exp_knob("MG_EXP_CHUNKS_SWEEP", 0);
-    if (forced > 0 && planes >= 100) nchunks = forced;
     int CI = (int)((planes + nchunks - 1) / nchunks);
     int cstride = CI, rhi = (int)r.hi;
     if (r2.hi > r2.lo) {
@@ -654,15 +676,21 @@ static void launch_sweep_t(hipStream_t s, View uin, View uout, View rhs, View ec
     }
     const WgOrder order{nchunks * tiles, blocked ? 1 : 0};
     const unsigned grid = order.grid();
-#define LAUNCH(MODE)                                                                                 \
-    hipLaunchKernelGGL((k_sweep_rb<WJ, WKP, D, NT, MODE>), dim3(grid), dim3(NT), 0, s, uin, uout, rhs, \
-                       ec, (int)n[0], (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k, (int)r.lo, \
+#define LAUNCH_F(MODE, FAST)                                                                               \
+    hipLaunchKernelGGL((k_sweep_rb<WJ, WKP, D, NT, MODE, FAST>), dim3(grid), dim3(NT), 0, s, uin, uout, rhs, \
+                       ec, (int)n[0], (int)n[1], (int)n[2], c, omega, CI, nchunks, tiles_k, (int)r.lo,       \
                        rhi, order, cstride)
+#define LAUNCH(MODE)                     \
+    do {                                 \
+        if (c.fast) LAUNCH_F(MODE, true); \
+        else LAUNCH_F(MODE, false);      \
+    } while (0)
     if (load_op == kLoadCorrect) LAUNCH(kLoadCorrect);
     else if (load_op == kLoadProlong) LAUNCH(kLoadProlong);
     else if (load_op == kLoadProlongZero) LAUNCH(kLoadProlongZero);
     else LAUNCH(kLoadPlain);
 #undef LAUNCH
+#undef LAUNCH_F
 }
 
 // One full red-black sweep u_in -> u_out: planes r of u_out, updated over 1..n-2 per axis

@@ -36,7 +36,7 @@ __device__ __forceinline__ double pick(d2 v, int e) { return e ? v.y : v.x; }
 
 constexpr int kTileJ = 12, kTileK = 28;  // owned rows / columns of a tile; + 4 = 16 rows, 16 pairs
 
-template <int TI>
+template <int TI, bool FAST>
 __global__ __launch_bounds__(256) void k_sweep_tile(View uin, View uout, View rhs, int nI, int nJ, int nK, Coef c,
                                                      double omega, int tiles_j, int tiles_k, int tiles_i1, int lo1,
                                                      int hi1, int lo2, int hi2)
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_sweep_tile(View uin, View uout, View rh
     // `colour`, where xok / yok allows it.  publish: the new value also goes to the image.
     auto phase = [&](auto qa_, auto qb_, int colour, bool xok, bool yok, bool publish) {
         constexpr int QA = decltype(qa_)::value, QB = decltype(qb_)::value, N = QB - QA;
-        double x[N], g[N];
+        double bb[N], si[N], sj[N], sk[N], u0[N], g[N];
         int e[N];
 #pragma unroll
         for (int t = 0; t < N; t++) {
@@ -117,18 +117,19 @@ __global__ __launch_bounds__(256) void k_sweep_tile(View uin, View uout, View rh
             const double *F = (e[t] ? X : Y) + q * PLANE + at;   // the other element's: the far k neighbour
             const double mate = pick(v[q], 1 - e[t]);
             const double far = e[t] ? F[1] : F[-1];
-            const double kz = e[t] ? mate + far : far + mate;    // u[k-1] + u[k+1]
-            x[t] = pick(rb[q], e[t]) + c.cx * (pick(v[q - 1], e[t]) + pick(v[q + 1], e[t])) + c.cy * (E[up] + E[dn]) +
-                   c.cz * kz;
+            bb[t] = pick(rb[q], e[t]);
+            si[t] = pick(v[q - 1], e[t]) + pick(v[q + 1], e[t]);
+            sj[t] = E[up] + E[dn];
+            sk[t] = e[t] ? mate + far : far + mate;              // u[k-1] + u[k+1]
+            u0[t] = pick(v[q], e[t]);
         }
-        div_d_n<N>(x, c, g);
+        sor_n<FAST, N>(bb, si, sj, sk, u0, c, omega, g);
 #pragma unroll
         for (int t = 0; t < N; t++) {
             const int q = QA + t;
             const int gi = gi0 + q;
             const bool ok = (e[t] ? yok : xok) && gi >= 1 && gi <= nI - 2;
-            const double u0 = pick(v[q], e[t]);
-            const double un = ok ? u0 + omega * (g[t] - u0) : u0;
+            const double un = ok ? g[t] : u0[t];
             if (e[t]) v[q].y = un;
             else v[q].x = un;
             if (publish) (e[t] ? Y : X)[q * PLANE + at] = un;
@@ -156,8 +157,12 @@ void launch_tile(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3
     const int tiles_i1 = (int)((r.hi - r.lo + TI - 1) / TI);
     const int tiles_i2 = r2.hi > r2.lo ? (int)((r2.hi - r2.lo + TI - 1) / TI) : 0;
     const unsigned grid = (unsigned)(tiles_j * tiles_k) * (unsigned)(tiles_i1 + tiles_i2);
-    hipLaunchKernelGGL((k_sweep_tile<TI>), dim3(grid), dim3(256), 0, s, uin, uout, rhs, (int)n[0], (int)n[1], (int)n[2], c,
-                       omega, tiles_j, tiles_k, tiles_i1, (int)r.lo, (int)r.hi, (int)r2.lo, (int)r2.hi);
+    if (c.fast)
+        hipLaunchKernelGGL((k_sweep_tile<TI, true>), dim3(grid), dim3(256), 0, s, uin, uout, rhs, (int)n[0], (int)n[1],
+                           (int)n[2], c, omega, tiles_j, tiles_k, tiles_i1, (int)r.lo, (int)r.hi, (int)r2.lo, (int)r2.hi);
+    else
+        hipLaunchKernelGGL((k_sweep_tile<TI, false>), dim3(grid), dim3(256), 0, s, uin, uout, rhs, (int)n[0], (int)n[1],
+                           (int)n[2], c, omega, tiles_j, tiles_k, tiles_i1, (int)r.lo, (int)r.hi, (int)r2.lo, (int)r2.hi);
 }
 
 }  // namespace

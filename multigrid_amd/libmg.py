@@ -21,6 +21,7 @@ MG_TRANSPORT_RCCL, MG_TRANSPORT_LOCAL, MG_TRANSPORT_NONE = 0, 1, 2
 MG_FLAG_KEEP_FINE_RESIDUAL = 1
 MG_FLAG_RESTRICT_7PT = 2
 MG_FLAG_RESERVE_EF = 4
+MG_FLAG_FAST_SMOOTHER = 8
 
 TIMER_KINDS = ("smooth_fine", "residual", "restrict", "smooth_coarse", "prolong",
                "prolong_correct", "norm", "ef")
@@ -469,10 +470,11 @@ class DistRank:
     same arguments apart from rank and device; creation, vcycles, solve and close are collective."""
 
     def __init__(self, n, dh, depth, rank, world, device=0, unique_id=None, local_group=None, coarse_cut=0,
-                 nu=None, omega=None, overlap=True, alone=False):
+                 nu=None, omega=None, overlap=True, alone=False, flags=0):
         self.n = tuple(int(a) for a in n)
         dc = MgDistConfig()
         dc.base = default_config(self.n, dh, depth, device)
+        dc.base.flags |= flags
         if nu is not None:
             for l, v in enumerate(nu):
                 dc.base.nu[l] = v

@@ -104,6 +104,41 @@ void orc_smooth_rb(double *u, const int64_t un[3], const double *rhs,
                                      IDX(i, j, k, rn[1], rn[2]), si, sj, c, omega);
 }
 
+/* The red-black sweep with the point update in its short form (the HIP library's
+ * MG_FLAG_FAST_SMOOTHER; no counterpart in the reference, whose update is smooth_point above): the
+ * division by d and omega are folded into the coefficients,
+ *   wb = omega*(1/d), wx = (omega*cx)*(1/d), wy, wz alike, wu = 1 - omega
+ *   u = fma(wz, u[k-1]+u[k+1], fma(wy, u[j-1]+u[j+1], fma(wx, u[i-1]+u[i+1], fma(wb, b, wu*u))))
+ * Equal to smooth_point up to rounding; this twin exists so that the GPU's short form can be
+ * checked bit for bit. */
+static inline void smooth_point_fast(double *u, const double *rhs, int div_eps0,
+                                     int64_t iu, int64_t ir, int64_t si, int64_t sj,
+                                     const double w[5])
+{
+    double b = div_eps0 ? rhs[ir] / ORC_EPS_0 : rhs[ir];
+    double t = w[4] * u[iu];
+    t = fma(w[0], b, t);
+    t = fma(w[1], u[iu - si] + u[iu + si], t);
+    t = fma(w[2], u[iu - sj] + u[iu + sj], t);
+    u[iu] = fma(w[3], u[iu - 1] + u[iu + 1], t);
+}
+
+void orc_smooth_rb_fast(double *u, const int64_t un[3], const double *rhs,
+                        const int64_t rn[3], const int64_t n[3], const double c[4],
+                        double omega, int sweeps, int div_eps0)
+{
+    const int64_t si = un[1] * un[2], sj = un[2];
+    const double rd = 1.0 / c[3];
+    const double w[5] = {omega * rd, (omega * c[0]) * rd, (omega * c[1]) * rd, (omega * c[2]) * rd, 1.0 - omega};
+    for (int s = 0; s < sweeps; s++)
+        for (int colour = 0; colour < 2; colour++)
+            for (int64_t i = 1; i < n[0] - 1; i++)
+                for (int64_t j = 1; j < n[1] - 1; j++)
+                    for (int64_t k = 1 + ((i + j + 1 + colour) & 1); k < n[2] - 1; k += 2)
+                        smooth_point_fast(u, rhs, div_eps0, IDX(i, j, k, un[1], un[2]),
+                                          IDX(i, j, k, rn[1], rn[2]), si, sj, w);
+}
+
 /* R = A*phi - b on the fine mesh; on the six faces R = phi - 0
  * (cpp/PotentialSolver.cpp:2656-2669, :3792-3805).  Returns sum of R^2 over all
  * nodes in i,j,k order (:3810-3816). */
@@ -355,14 +390,17 @@ typedef void (*smooth_fn)(double *, const int64_t *, const double *, const int64
 /* The iteration loop of solve() (cpp/PotentialSolver.cpp:3756-4216 for V5; the
  * other depths are the same text with fewer levels): smooth, residual, norm and
  * termination test, restrict down, then (smooth, prolong) up, correct.
- * rb != 0 selects the red-black ordering for every smoother call.
+ * rb != 0 selects the red-black ordering for every smoother call (rb == 2: on the levels >= 1
+ * with the point update in its short form, orc_smooth_rb_fast, as the HIP library's
+ * MG_FLAG_FAST_SMOOTHER does).
  * l2_hist (may be NULL) receives the norm observed in each iteration.
  * Returns 1 when L2 < tol was observed, else 0; *cycles = iterations whose
  * residual was evaluated (the converged one included). */
 int orc_solve(orc_solver *s, double *phi, const double *rho, unsigned max_it,
               double tol, int rb, unsigned *cycles, double *L2_out, double *l2_hist)
 {
-    smooth_fn smooth = rb ? orc_smooth_rb : orc_smooth_lex;
+    smooth_fn smooth = rb ? orc_smooth_rb : orc_smooth_lex;              /* fine grid */
+    smooth_fn smooth_c = rb == 2 ? orc_smooth_rb_fast : smooth;          /* levels >= 1 */
     const int L = s->depth;
     double c[ORC_MAX_LEVELS][4];
     for (int l = 0; l <= L; l++) orc_coeffs(s->dh, l, c[l]);
@@ -381,10 +419,10 @@ int orc_solve(orc_solver *s, double *phi, const double *rho, unsigned max_it,
             if (s->restrict7) orc_restrict7(s->R[l], s->n[l], s->R[l + 1], s->n[l + 1]);
             else orc_restrict27(s->R[l], s->n[l], s->R[l + 1], s->n[l + 1]);
         }
-        smooth(s->eps[L], s->en[L], s->R[L], s->n[L], s->n[L], c[L], s->omega, s->nu[L], 0);
+        smooth_c(s->eps[L], s->en[L], s->R[L], s->n[L], s->n[L], c[L], s->omega, s->nu[L], 0);
         for (int l = L - 1; l >= 1; l--) {
             orc_prolong(s->eps[l + 1], s->en[l + 1], s->eps[l], s->en[l], s->n[l]);
-            smooth(s->eps[l], s->en[l], s->R[l], s->n[l], s->n[l], c[l], s->omega, s->nu[l], 0);
+            smooth_c(s->eps[l], s->en[l], s->R[l], s->n[l], s->n[l], c[l], s->omega, s->nu[l], 0);
         }
         orc_prolong(s->eps[1], s->en[1], s->eps[0], s->en[0], s->n[0]);
         orc_correct(phi, s->eps[0], N0);

@@ -66,6 +66,8 @@ def lib():
         L.orc_smooth_lex.restype = None
         L.orc_smooth_rb.argtypes = sm
         L.orc_smooth_rb.restype = None
+        L.orc_smooth_rb_fast.argtypes = sm
+        L.orc_smooth_rb_fast.restype = None
         L.orc_residual.argtypes = [_dp, _dp, _dp, _i64x3, _f64x4]
         L.orc_residual.restype = C.c_double
         L.orc_sumsq.argtypes = [_dp, C.c_int64]
@@ -134,9 +136,10 @@ def level_sizes(n0, depth):
     return [tuple(int(a) >> l for a in n0) for l in range(depth + 1)]
 
 
-def smooth(u, rhs, n, c, omega=1.4, sweeps=1, div_eps0=False, rb=False):
-    """In-place GS-SOR sweeps on u (lexicographic, or red-black when rb)."""
-    f = lib().orc_smooth_rb if rb else lib().orc_smooth_lex
+def smooth(u, rhs, n, c, omega=1.4, sweeps=1, div_eps0=False, rb=False, fast=False):
+    """In-place GS-SOR sweeps on u (lexicographic, or red-black when rb; fast: the red-black sweep
+    with the point update in its short form, the HIP library's MG_FLAG_FAST_SMOOTHER)."""
+    f = lib().orc_smooth_rb_fast if fast else lib().orc_smooth_rb if rb else lib().orc_smooth_lex
     f(_p(u), _dims(u), _p(rhs), _dims(rhs), _i64x3(*n), _f64x4(*c), omega, sweeps, int(div_eps0))
     return u
 
@@ -250,9 +253,11 @@ class Solver:
             shp = tuple(a + 1 for a in shp)
         return self._view(lib().orc_solver_eps(self._h, l), shp)
 
-    def solve(self, phi, rho, max_it=10000, tol=1e-4, rb=False):
-        """Runs the reference iteration loop in place on phi.
-        Returns (converged, cycles, L2, l2_history)."""
+    def solve(self, phi, rho, max_it=10000, tol=1e-4, rb=False, fast=False):
+        """Runs the reference iteration loop in place on phi (rb: red-black smoother; fast: red-black
+        with the short-form point update on the levels >= 1).  Returns (converged, cycles, L2, l2_history)."""
+        if fast:
+            rb = 2
         hist = np.zeros(max_it)
         cyc = C.c_uint(0)
         l2 = C.c_double(0)
