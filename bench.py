@@ -299,6 +299,25 @@ def run_single(args):
     print(json.dumps(out))
 
 
+def slab_profiled_traffic(n, world):
+    """HBM bytes of the dominant launch on one rank's slab (the plain out-of-place sweep of the rank's
+    fine planes) from the committed rocprofv3 counter summary of that share, measured with the rank
+    alone on one GPU (tools/profile_slab.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes,
+    FETCH_SIZE doubled).  None where no summary of this configuration is committed."""
+    name = {(1025, 8): "r03b_slab_mid", (1025, 4): "r03b_slab_w4", (1025, 2): "r03b_slab_w2",
+            (2049, 8): "r03b_slab2049_mid"}.get((n, world))
+    path = os.path.join(ROOT, "profiles", f"{name}_summary.json") if name else None
+    if not path or not os.path.exists(path):
+        return None, None
+    try:
+        prof = json.load(open(path))
+        best = max((v.get("hbm_bytes_max_launch", 0.0) for k, v in prof["kernels"].items()
+                    if k.startswith("k_sweep_rb<64, 32, 2, 512, 0")), default=0.0)
+        return (best or None), os.path.basename(path)
+    except Exception:
+        return None, None
+
+
 def sweep_roofline(libmg, n, planes, device):
     """HIP-event time of the dominant kernel on a slab of this rank's shape: one full red-black sweep
     (out of place) of `planes` owned planes of n x n nodes, launched on torch's current stream and
@@ -419,6 +438,7 @@ def run_distributed(args):
     dist.barrier()
 
     roofline = sweep_roofline(libmg, n, own[1] - own[0], local)
+    roofline["traffic"], roofline["traffic_source"] = slab_profiled_traffic(n, world)
     base1 = None
     if rank == 0 and not args.no_single_gpu_compare and n <= 1025:
         torch.cuda.empty_cache()

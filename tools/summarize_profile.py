@@ -73,7 +73,7 @@ def main(tag):
     out = {"tag": tag, "kernels": kern}
     if os.path.exists(os.path.join(src, "command.txt")):   # tools/profile_slab.sh
         out["command"] = open(os.path.join(src, "command.txt")).read().strip()
-        title = "one rank of the slab-partitioned 1025^3 V6 cycle, one MI355X"
+        title = "one rank of a slab-partitioned cycle, alone on one MI355X"
     else:
         bench = json.load(open(os.path.join(src, "bench_stats.json")))
         out["command"] = ("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 "
