@@ -9,25 +9,55 @@ if [ "${1:-}" = build ]; then
   mkdir -p "$out" && cd "$root/multigrid_amd/csrc" &&
   /opt/rocm/bin/hipcc -O1 -g --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off -fno-fast-math \
       -Wno-unused-value -pthread -Xarch_host -fsanitize=address -Xarch_host -fno-omit-frame-pointer \
-      mg_kernels.hip mg_sweep.hip mg_resrest.hip mg_ef.hip mg_api.hip mg_dist.hip -o "$out/libmg_hip.so" &&
+      mg_kernels.hip mg_sweep.hip mg_tile.hip mg_resrest.hip mg_ef.hip mg_api.hip mg_dist.hip -o "$out/libmg_hip.so" &&
   cd "$root/host" &&
   /opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -fsanitize=address -fno-omit-frame-pointer -o "$out/box_mg" \
       box_mg.cpp MultiGridSolverHIP.cpp PotentialSolver.cpp World.cpp Output.cpp -L"$out" -lmg_hip -Wl,-rpath,'$ORIGIN'
   exit $?
 fi
-export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0
+# Every case runs twice: with the default quarantine of freed blocks, and with none.  What is
+# counted per run: AddressSanitizer error reports, internal "CHECK failed" aborts of the sanitizer
+# runtime (with whether a frame of this repository's code is on their stack), and the exit status.
+# A case is clean only with no report, no CHECK and the driver's own exit status in BOTH runs --
+# except for the one known CHECK (sanitizer_allocator_device.h: dev_runtime_unloaded_), which is
+# listed as what it is: ROCm's sanitizer runtime recycling a quarantined block of its device
+# allocator from inside libamdhip64's static destructors (__cxa_finalize), after the HIP runtime
+# has unloaded, i.e. after main() has returned and every handle is destroyed.  With the quarantine
+# off the block is recycled when it is freed and the CHECK does not fire.
 B=$out/box_mg
 n=0
+bad=0
 while read -r args; do
   n=$((n + 1))
-  timeout -k 10 120 $B $args > /tmp/asan_$n.log 2>&1
-  rc=$?
-  echo "box_mg $args: rc=$rc asan_errors=$(grep -c 'ERROR: AddressSanitizer' /tmp/asan_$n.log) $(grep -m1 converged= /tmp/asan_$n.log)"
-  [ $rc -lt 124 ] || exit 1
+  for q in default 0; do
+    opts=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0
+    [ $q = 0 ] && opts=$opts:quarantine_size_mb=0
+    log=/tmp/asan_${n}_$q.log
+    ASAN_OPTIONS=$opts timeout -k 10 120 $B $args > $log 2>&1
+    rc=$?
+    errors=$(grep -c 'ERROR: AddressSanitizer' $log)
+    checks=$(grep -c 'AddressSanitizer: CHECK failed' $log)
+    known=$(grep -c 'CHECK failed: sanitizer_allocator_device.h.*dev_runtime_unloaded_' $log)
+    ours=$(grep -c -E 'libmg_hip|box_mg|MultiGridSolverHIP' <(grep -A40 'CHECK failed' $log | grep '^ *#'))
+    atexit=$(grep -c '__cxa_finalize' $log)
+    verdict=clean
+    if [ $errors -gt 0 ] || [ $rc -ge 124 ]; then verdict=FAILED
+    elif [ $checks -gt 0 ]; then
+      if [ $checks -eq $known ] && [ $ours -eq 0 ] && [ $atexit -gt 0 ]; then verdict="runtime-exit-check (no frame of this repository, under __cxa_finalize)"
+      else verdict=FAILED; fi
+    elif [ $rc -ne 0 ]; then verdict=FAILED
+    fi
+    [ "$verdict" = FAILED ] && bad=$((bad + 1))
+    echo "box_mg $args [quarantine=$q]: rc=$rc asan_errors=$errors check_failed=$checks -> $verdict | $(grep -m1 converged= $log)"
+    [ $rc -lt 124 ] || exit 1
+  done
 done <<'CASES'
 41 2 1e-6 --again
 33 0 1e-6 --vti /tmp/asan.vti
 65 3 1e-6 --pageable --dump /tmp/asan_phi.bin
 65 3 1e-6 --b
 129 3 1e-6 --gpus 0,0 --again
+41 2 1e-6 --edit face --max-it 40 --assume-untouched
 CASES
+echo "cases not clean: $bad"
+[ $bad -eq 0 ]
