@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--cpu-cycles", type=int, default=3, help="cycles of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-solve", action="store_true", help="skip the time-to-1e-6 solve")
     ap.add_argument("--tol", type=float, default=1e-6)
+    ap.add_argument("--no-fast", action="store_true", help="skip the extra leg that times MG_FLAG_FAST_SMOOTHER")
+    ap.add_argument("--flags", type=int, default=0, help="MG_FLAG_* bits for the timed handle (profiling aid; "
+                                                          "named in config.workload when set)")
     ap.add_argument("--no-single-gpu-compare", action="store_true",
                     help="N>1: skip timing the same workload on one GPU of the node")
     return ap.parse_args()
@@ -122,7 +125,7 @@ def run_single(args):
     rho = problem.synthetic_rho(N)
     npts = float(n) ** 3
 
-    h = libmg.Handle(N, dh, depth, device=0)
+    h = libmg.Handle(N, dh, depth, device=0, flags=args.flags)
     h.set_rho(rho)
     h.set_phi(np.zeros(N))
     if args.warmup:
@@ -257,31 +260,32 @@ def run_single(args):
     # one chain of fused multiply-adds, equal to the reference's expression up to rounding; the fine
     # sweep, residual, restriction, prolongation and the norm stay exact).  Reported beside the
     # headline, never as it.
-    hf = libmg.Handle(N, dh, depth, device=0, flags=libmg.MG_FLAG_FAST_SMOOTHER)
-    hf.set_rho(rho)
-    hf.set_phi(np.zeros(N))
-    hf.vcycles(max(1, args.warmup))
-    t0 = time.perf_counter()
-    hf.vcycles(args.steps)
-    wf = time.perf_counter() - t0
-    hf.set_profiling(True)
-    hf.reset_timers()
-    hf.vcycles(5)
-    tf = hf.timers()
-    hf.set_profiling(False)
-    fast = {"ms_per_step": wf * 1e3 / args.steps, "gdof_per_s": npts * args.steps / wf / 1e9,
-            "kernels_avg_us": {k: 1e3 * t["ms"] / t["launches"] for k, t in tf.items() if t["launches"]},
-            "what": "MG_FLAG_FAST_SMOOTHER: 8 instead of 22 fp64 operations per point update on the levels >= 1; "
-                    "not bit-identical to the reference's expression (rounding), checked against the oracle's twin "
-                    "of the same form"}
-    if not args.no_solve:
+    hf = None if args.no_fast else libmg.Handle(N, dh, depth, device=0, flags=libmg.MG_FLAG_FAST_SMOOTHER)
+    if hf is not None:
+        hf.set_rho(rho)
         hf.set_phi(np.zeros(N))
-        hf.reset_state()
+        hf.vcycles(max(1, args.warmup))
         t0 = time.perf_counter()
-        ok, cycles, l2s = hf.solve(10000, args.tol)
-        fast["solve"] = {"converged": ok, "cycles": cycles, "seconds": time.perf_counter() - t0, "L2": l2s}
-    hf.close()
-    extras["fast_smoother"] = fast
+        hf.vcycles(args.steps)
+        wf = time.perf_counter() - t0
+        hf.set_profiling(True)
+        hf.reset_timers()
+        hf.vcycles(5)
+        tf = hf.timers()
+        hf.set_profiling(False)
+        fast = {"ms_per_step": wf * 1e3 / args.steps, "gdof_per_s": npts * args.steps / wf / 1e9,
+                "kernels_avg_us": {k: 1e3 * t["ms"] / t["launches"] for k, t in tf.items() if t["launches"]},
+                "what": "MG_FLAG_FAST_SMOOTHER: 8 instead of 22 fp64 operations per point update on the levels >= 1; "
+                        "not bit-identical to the reference's expression (rounding), checked against the oracle's twin "
+                        "of the same form"}
+        if not args.no_solve:
+            hf.set_phi(np.zeros(N))
+            hf.reset_state()
+            t0 = time.perf_counter()
+            ok, cycles, l2s = hf.solve(10000, args.tol)
+            fast["solve"] = {"converged": ok, "cycles": cycles, "seconds": time.perf_counter() - t0, "L2": l2s}
+        hf.close()
+        extras["fast_smoother"] = fast
 
     cpu = cpu_baseline(n, depth, args.cpu_cycles) if args.cpu_cycles > 0 else None
 
@@ -290,7 +294,8 @@ def run_single(args):
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"{n}^3 fp64 multigrid V{depth} cycle (sweeps {list(h.cfg.nu[:depth + 1])}, omega 1.4), "
-                                  f"red-black GS-SOR, 1 GPU", "grid": n, "depth": depth},
+                                  f"red-black GS-SOR, 1 GPU" + (f", MG_FLAG bits {args.flags}" if args.flags else ""),
+                      "grid": n, "depth": depth},
            "vcycles_per_s": vps, "device_ms_per_step": dev_ms / args.steps, "last_L2": l2,
            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "solve": solve,
            "next_rows": extras}

@@ -97,13 +97,13 @@ def measure(n, world, rank, cycles=10, overlap=True, cut=None):
     return out
 
 
-def measure_cxx(n, world, rank, cycles=10, overlap=True, cut=None):
+def measure_cxx(n, world, rank, cycles=10, overlap=True, cut=None, flags=0):
     """The same share driven by mg_dist (the product's driver): device time of `cycles` cycles."""
     from multigrid_amd import libmg
     N = (n, n, n)
     depth = problem.reference_depth_for(N)
     d = libmg.DistRank(N, problem.main_extents_dh(N), depth, rank, world, device=0, coarse_cut=cut or 0,
-                       overlap=overlap, alone=True)
+                       overlap=overlap, alone=True, flags=flags)
     d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
     d.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
     d.vcycles(2)
@@ -120,11 +120,17 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="whole-slab launches, no edge/interior split")
     ap.add_argument("--cut", type=int, default=None, help="first level solved whole on rank 0 (default: first with <= 128 planes)")
     ap.add_argument("--python", action="store_true", help="time the Python twin of the schedule, level by level")
+    ap.add_argument("--fast", action="store_true", help="MG_FLAG_FAST_SMOOTHER (C++ driver only)")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     for case in args.cases.split(","):
         w, r = (int(x) for x in case.split(":"))
-        res = (measure if args.python else measure_cxx)(args.size, w, r, overlap=not args.no_overlap, cut=args.cut)
+        if args.python:
+            res = measure(args.size, w, r, overlap=not args.no_overlap, cut=args.cut)
+        else:
+            from multigrid_amd import libmg
+            res = measure_cxx(args.size, w, r, overlap=not args.no_overlap, cut=args.cut,
+                              flags=libmg.MG_FLAG_FAST_SMOOTHER if args.fast else 0)
         print(" ".join(f"{k}={v:.3f}" if isinstance(v, float) else f"{k}={v}" for k, v in res.items()), flush=True)
 
 
