@@ -773,6 +773,15 @@ struct mg_dist {
 
     // Levels cut..L on whole arrays (every rank its own): restrict down, smooth the coarsest,
     // (prolong, smooth) back up to level `cut`.
+    //
+    // Of eps_cut a rank only ever reads the planes under its own slab of level cut-1, and a sweep
+    // needs its input two planes further out on either side than it produces (red on the next
+    // plane, black on the plane itself).  So sweep s of nu runs on those planes widened by
+    // 2*(nu-s), the prolongation before the first sweep on the range widened by 2*nu, and the
+    // level below is needed on the planes that prolongation reads, and so on down.  A level is
+    // cut down this way when that leaves at most half of it (1025^3 over 8 ranks: 40 of the 129
+    // planes of level 3 at the start, 24 at the end); every value computed is the one the whole
+    // sweep would give, since nothing outside a range is read later.
     int coarse_levels()
     {
         int64_t n[3];
@@ -780,12 +789,31 @@ struct mg_dist {
             plan.level_n(l, n);
             mgk::restrict27(stream, cR[l].v, cR[l + 1].v, n, IRange{0, plan.planes(l + 1, false)});
         }
+        const auto widen = [](IRange r, int64_t by, int64_t top) {
+            return IRange{r.lo - by < 0 ? 0 : r.lo - by, r.hi + by > top ? top : r.hi + by};
+        };
+        IRange last[MG_MAX_LEVELS], first[MG_MAX_LEVELS];  // planes of eps_l after its last sweep / before its first
+        IRange need = plan.stored(cut - 1, cut > 1, rank, H_U);  // planes of level cut-1 formed from eps_cut
+        for (int l = cut; l <= L; l++) {
+            const int64_t top = plan.planes(l, true);
+            // the prolongation onto fine planes [lo, hi) reads coarse planes lo/2 .. hi/2
+            last[l] = IRange{need.lo >> 1, (need.hi >> 1) + 1 > top ? top : (need.hi >> 1) + 1};
+            first[l] = widen(last[l], 2 * (int64_t)nu[l], top);
+            if (l == L || world == 1 || 2 * (first[l].hi - first[l].lo) > top) last[l] = first[l] = IRange{0, top};
+            need = first[l];
+        }
         for (int l = L; l >= cut; l--) {
             plan.level_n(l, n);
-            if (l < L) mgk::prolong(stream, ceps[l + 1].v, ceps[l].v, n, IRange{0, n[0]});
+            const int64_t top = plan.planes(l, true);
+            if (l < L) mgk::prolong(stream, ceps[l + 1].v, ceps[l].v, n, IRange{first[l].lo, first[l].hi > n[0] ? n[0] : first[l].hi});
             View vu = ceps[l].v, va = ceps_alt[l].v;
             const double *before = vu.p;
-            mgk::smooth_rb(stream, &vu, &va, cR[l].v, n, c[l], omega, nu[l], IRange{0, vu.d[0]});
+            if (first[l].lo == 0 && first[l].hi == top) {
+                mgk::smooth_rb(stream, &vu, &va, cR[l].v, n, c[l], omega, nu[l], IRange{0, top});
+            } else {
+                for (int s = 1; s <= nu[l]; s++)
+                    mgk::smooth_rb(stream, &vu, &va, cR[l].v, n, c[l], omega, 1, widen(last[l], 2 * (int64_t)(nu[l] - s), top));
+            }
             if (vu.p != before) std::swap(ceps[l], ceps_alt[l]);
         }
         HIP_TRY(hipGetLastError());

@@ -129,23 +129,47 @@ __global__ __launch_bounds__(NT) void k_smooth_lds(View u, View rhs, int nI, int
         }
     __syncthreads();
     const int si = uJ * H, sj = H;
+    // How many of a wave's P point slots hold a point in any lane (the slots fill in order of q, so
+    // the used ones are a prefix).  A wave skips the slots that are empty in all its lanes: with
+    // 1372 points per colour on 1024 threads, ten of the sixteen waves have nothing in slot 1.
+    int used[2];
+#pragma unroll
+    for (int colour = 0; colour < 2; colour++) {
+        used[colour] = 0;
+#pragma unroll
+        for (int q = 0; q < P; q++)
+            if (__builtin_amdgcn_readfirstlane(__any(off[colour][q] >= 0))) used[colour] = q + 1;
+    }
     for (int s = 0; s < sweeps; s++) {
 #pragma unroll
         for (int colour = 0; colour < 2; colour++) {
-            double ti[P], tj[P], tk[P], un[P];
-#pragma unroll
-            for (int q = 0; q < P; q++) {
-                // a thread without a point reads around some interior entry and discards the result
+            // a thread without a point reads around some interior entry and discards the result
+            auto gather = [&](int q, double &ti, double &tj, double &tk) {
                 const int o = off[colour][q] < 0 ? (1 - colour) * HALF + si + sj + 1 : off[colour][q];
                 const double *p = su + o;
                 const double *pk = p + kodd[colour][q];
-                ti[q] = p[-si] + p[si];
-                tj[q] = p[-sj] + p[sj];
-                tk[q] = pk[-1] + pk[0];
-            }
-            sor_n<FAST, P>(b[colour], ti, tj, tk, cur[colour], c, omega, un);  // the quotients of a thread's points behind one branch
+                ti = p[-si] + p[si];
+                tj = p[-sj] + p[sj];
+                tk = pk[-1] + pk[0];
+            };
+            if (used[colour] == P) {
+                double ti[P], tj[P], tk[P], un[P];
 #pragma unroll
-            for (int q = 0; q < P; q++) cur[colour][q] = un[q];
+                for (int q = 0; q < P; q++) gather(q, ti[q], tj[q], tk[q]);
+                sor_n<FAST, P>(b[colour], ti, tj, tk, cur[colour], c, omega, un);  // the quotients of a thread's points behind one branch
+#pragma unroll
+                for (int q = 0; q < P; q++) cur[colour][q] = un[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < P - 1; q++)
+                    if (q < used[colour]) {
+                        double ti[1], tj[1], tk[1], un[1];
+                        const double bq[1] = {b[colour][q]}, uq[1] = {cur[colour][q]};
+                        gather(q, ti[0], tj[0], tk[0]);
+                        sor_n<FAST, 1>(bq, ti, tj, tk, uq, c, omega, un);
+                        cur[colour][q] = un[0];
+                    }
+            }
 #pragma unroll
             for (int q = 0; q < P; q++)  // own entry: same (i, j, k>>1), this colour's half
                 if (off[colour][q] >= 0) su[off[colour][q] + (colour ? HALF : -HALF)] = cur[colour][q];
@@ -447,11 +471,14 @@ bool wg_order_blocked() { return true; }
 // Plane ranges up to this length go to the tile kernel even where the marching kernel could run (the
 // two planes next to a slab neighbour: a march over them is all lead-in planes and start-up).
 // Measured on 32 planes of 257^2 / 513^2: the march 14 / 36 us, tiles 21 / 71 us; on 2 planes of
-// 257^2: the march 8 us, tiles 4 us.
-static int tile_max_planes()
+// 257^2: the march 8 us, tiles 4 us.  Planes of 129^2, the smallest the march takes: 40 planes 13.4
+// (in pairs 11.2 per sweep) against 9.1 us, 24 planes 12.1 against 7.8, all 129 planes 16.1 per
+// sweep in pairs against 19.7.
+static int tile_max_planes(const View &u)
 {
     static const int v = exp_knob("MG_EXP_TILE_PLANES", 2);
-    return v;
+    static const int small = exp_knob("MG_EXP_TILE_PLANES_SMALL", 48);
+    return u.d[1] * u.d[2] <= 136 * 136 && small > v ? small : v;
 }
 static bool use_tile_sweep() { static const int v = exp_knob("MG_EXP_NO_TILE", 0); return v == 0; }
 
@@ -497,7 +524,7 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
 #undef LDS_LAUNCH
         return 1;
     }
-    const bool tile = alt && alt->p && use_tile_sweep() && (!use_fused_sweep(*u) || r.hi - r.lo <= tile_max_planes());
+    const bool tile = alt && alt->p && use_tile_sweep() && (!use_fused_sweep(*u) || r.hi - r.lo <= tile_max_planes(*u));
     const bool fused = !tile && alt && alt->p && use_fused_sweep(*u);
     // two sweeps per launch where the stored planes reach four beyond the range (always, for a
     // whole array; a slab with two halo planes exchanges between sweeps instead)

@@ -177,8 +177,10 @@ void sweep_rb_tile(hipStream_t s, View uin, View uout, View rhs, const int64_t n
     const int64_t planes = r.hi - r.lo;
     // planes per tile: few for short ranges and small levels (more workgroups), more for large
     // planes (each tile re-reads four planes of halo)
-    // (measured per sweep, 34^3: 3.8 / 4.4 / 5.5 us with 2 / 4 / 8 planes per tile; 66^3: 7.3 - 7.5 us alike)
-    int ti = planes <= 2 ? 2 : (planes <= 4 || uin.d[1] * uin.d[2] <= 80 * 80) ? 4 : 8;
+    // (measured per sweep with 2 / 4 / 8 planes per tile, 34^3: 3.8 / 4.4 / 5.5 us; 66^3: 7.3 - 7.5 us
+    // alike; 40 planes of 129^2: 10.0 / 9.1 / 9.7)
+    const int64_t area = uin.d[1] * uin.d[2];
+    int ti = (planes <= 2 || area <= 40 * 40) ? 2 : (planes <= 4 || area <= 136 * 136) ? 4 : 8;
     if (shape) ti = shape;
     if (ti == 2) launch_tile<2>(s, uin, uout, rhs, n, c, omega, r, r2);
     else if (ti == 4) launch_tile<4>(s, uin, uout, rhs, n, c, omega, r, r2);

@@ -546,18 +546,44 @@ class DistSolver:
         # step 6), phi -= P(eps_1), waits for the next iteration's first fine sweep
         self.correction_pending = True
 
+    def _coarse_ranges(self):
+        """Per whole level l: (first, last) = the planes of eps_l that must be right before its first
+        and after its last sweep.  A rank reads of eps_cut only the planes under its own slab of
+        level cut-1, and a sweep needs its input two planes further out on either side than it
+        produces; a level is cut down this way when that leaves at most half of it."""
+        P, L, H = self.plan, self.depth, 2
+        need = P.stored(self.cut - 1, "eps" if self.cut > 1 else "phi", self.rank, H)
+        first, last = {}, {}
+        for l in range(self.cut, L + 1):
+            top = P.planes(l, "eps")
+            last[l] = (need[0] >> 1, min((need[1] >> 1) + 1, top))
+            first[l] = (max(last[l][0] - 2 * self.nu[l], 0), min(last[l][1] + 2 * self.nu[l], top))
+            if l == L or self.world == 1 or 2 * (first[l][1] - first[l][0]) > top:
+                first[l] = last[l] = (0, top)
+            need = first[l]
+        return first, last
+
     def _coarse_levels(self):
         """Levels cut..depth on whole arrays (every rank its own): restrict down, smooth the coarsest,
-        (prolong, smooth) back up to level `cut`."""
+        (prolong, smooth) back up to level `cut`, each level on the planes `_coarse_ranges` names."""
         P, ops, L = self.plan, self.ops, self.depth
         for l in range(self.cut, L):
             ops.restrict27(self.cR[l], self.cR[l + 1], P.level_n(l), 0, P.planes(l + 1, "R"))
+        first, last = self._coarse_ranges()
         for l in range(L, self.cut - 1, -1):
+            top = P.planes(l, "eps")
             if l < L:
-                ops.prolong(self.ceps[l + 1], self.ceps[l], P.level_n(l), 0, P.planes(l, "R"), False)
+                ops.prolong(self.ceps[l + 1], self.ceps[l], P.level_n(l), first[l][0], min(first[l][1], P.planes(l, "R")), False)
             u, alt = self.ceps[l], self.ceps_alt[l]
-            if ops.smooth(u, alt, self.cR[l], P.level_n(l), self.coef[l], self.omega, self.nu[l], 0, u.planes):
-                self.ceps[l], self.ceps_alt[l] = alt, u
+            if first[l] == (0, top):
+                if ops.smooth(u, alt, self.cR[l], P.level_n(l), self.coef[l], self.omega, self.nu[l], 0, top):
+                    u, alt = alt, u
+            else:
+                for s in range(1, self.nu[l] + 1):
+                    w = 2 * (self.nu[l] - s)
+                    if ops.smooth(u, alt, self.cR[l], P.level_n(l), self.coef[l], self.omega, 1, max(last[l][0] - w, 0), min(last[l][1] + w, top)):
+                        u, alt = alt, u
+            self.ceps[l], self.ceps_alt[l] = u, alt
 
     def l2(self, s=None):
         s = self.last_sum if s is None else s

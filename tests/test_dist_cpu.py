@@ -20,7 +20,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, depth, cut, cycles, out_dir, oop=False):
+def _worker(rank, world, port, n, depth, cut, cycles, out_dir, oop=False, nu=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -28,7 +28,7 @@ def _worker(rank, world, port, n, depth, cut, cycles, out_dir, oop=False):
         from multigrid_amd import dist as mgd, problem
         from oracle_ops import OracleOps
         N = (n, n, n)
-        s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, OracleOps(bool(oop)), mgd.Comm(defer=oop == 2), cut=cut)
+        s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, OracleOps(bool(oop)), mgd.Comm(defer=oop == 2), cut=cut, nu=nu)
         s.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
         s.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
         hist = []
@@ -41,6 +41,10 @@ def _worker(rank, world, port, n, depth, cut, cycles, out_dir, oop=False):
         np.save(os.path.join(out_dir, f"lo_{rank}.npy"), np.array([lo]))
         if rank == 0:
             np.save(os.path.join(out_dir, "hist.npy"), np.array(hist))
+        if nu is not None:
+            first, _ = s._coarse_ranges()
+            np.save(os.path.join(out_dir, f"first_{rank}.npy"), np.array([first[l][1] - first[l][0] for l in range(s.cut, depth + 1)]))
+            return
         # the solve loop: all ranks must agree on the stopping iteration
         s2 = mgd.DistSolver(N, problem.main_extents_dh(N), depth, OracleOps(bool(oop)), mgd.Comm(defer=oop == 2), cut=cut)
         s2.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
@@ -87,6 +91,30 @@ def test_partitioned_cycle_equals_undivided_oracle(orc, tmp_path, world, n, dept
         s = np.load(tmp_path / f"solve_{r}.npy")
         assert (bool(s[0]), int(s[1])) == (ok, cyc)
         assert s[2] == pytest.approx(l2, rel=1e-12)
+
+
+@pytest.mark.parametrize("world,n,depth,cut,nu,oop", [(8, 129, 3, 1, (1, 2, 1, 6), 1), (8, 129, 3, 1, (1, 2, 1, 6), 0),
+                                                      (4, 65, 3, 1, (2, 1, 1, 4), 2), (8, 129, 4, 2, (1, 3, 1, 1, 5), 1)],
+                         ids=str)
+def test_whole_levels_cut_down_to_what_a_rank_needs(orc, tmp_path, world, n, depth, cut, nu, oop):
+    """Every rank runs the levels below the partition, each only on the planes from which its own
+    slab can be reached (two planes more per side for every sweep still to come).  Short sweep
+    schedules make those ranges small on small grids; the assembled phi must not change."""
+    cycles = 3
+    mp.spawn(_worker, args=(world, free_port(), n, depth, cut, cycles, str(tmp_path), oop, nu), nprocs=world, join=True)
+    N = (n, n, n)
+    want = np.zeros(N)
+    _, _, _, hist = orc.Solver(N, orc.main_extents_dh(N), depth, nu=nu).solve(want, orc.synthetic_rho(N), cycles, 0.0, rb=True)
+    got = np.zeros(N)
+    for r in range(world):
+        lo = int(np.load(tmp_path / f"lo_{r}.npy")[0])
+        part = np.load(tmp_path / f"phi_{r}.npy")
+        got[lo:lo + part.shape[0]] = part
+    assert_bit_equal(got, want, "phi assembled from the slabs")
+    assert np.load(tmp_path / "hist.npy") == pytest.approx(hist, rel=1e-12)
+    # the case does exercise cut-down levels: some rank runs the first whole level on less than all of it
+    whole = (n >> cut) + 1
+    assert min(int(np.load(tmp_path / f"first_{r}.npy")[0]) for r in range(world)) < whole
 
 
 def test_plan_partitions_every_level(mg):

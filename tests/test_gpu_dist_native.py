@@ -257,6 +257,38 @@ def test_extreme_partitions_equal_the_undivided_handle(gpu, n, depth, world, cut
         assert_bit_equal(h.compute_ef(), ef, "E of the slabs")
 
 
+@pytest.mark.parametrize("n,depth,world,cut,nu", [
+    ((129, 129, 129), 3, 8, 1, (1, 2, 1, 6)),        # levels 1 and 2 cut down (65 and 33 planes), tiles
+    ((257, 257, 257), 4, 8, 1, (1, 3, 2, 1, 9)),     # level 1 = 129^3 cut down: tiles on ranges of planes the march could take
+    ((257, 257, 257), 4, 8, 2, None),                # the default schedule: 65 planes of level 2 cut down to 31
+    ((257, 140, 150), 3, 16, 2, (1, 1, 2, 5)),       # sixteen ranks, non-cubic
+    ((513, 72, 136), 4, 8, 2, (1, 5, 3, 2, 7)),      # 129 planes of 19 x 35 cut down
+    ((257, 600, 560), 3, 8, 1, (1, 3, 2, 6)),        # 129 planes of 301 x 281: the marching kernel on ranges of a whole array
+], ids=str)
+def test_whole_levels_cut_down_to_what_a_rank_needs(gpu, n, depth, world, cut, nu):
+    """Every rank runs the levels below the partition, each only on the planes from which its own
+    slab can be reached: two planes more per side for every sweep still to come, the level below
+    on what the prolongation onto that range reads.  Potential after three cycles, then after a
+    solve, against the undivided handle, bit for bit."""
+    from multigrid_amd import problem
+    dh = problem.main_extents_dh(n)
+    g = np.random.default_rng(19)
+    rho, phi0 = g.uniform(-1, 1, n) * 8.85e-9, g.uniform(-1, 1, n)
+    out = []
+    for devices in (None, [0] * world):
+        with gpu.Handle(n, dh, depth, nu=nu, devices=devices, coarse_cut=cut if devices else 0) as h:
+            h.set_rho(rho)
+            h.set_phi(phi0)
+            l2 = h.vcycles(3)
+            phi3 = h.get_phi()
+            ok, cycles, _ = h.solve(40, 1e-3)
+            out.append((l2, phi3, ok, cycles, h.get_phi()))
+    assert out[1][0] == pytest.approx(out[0][0], rel=1e-12)
+    assert_bit_equal(out[1][1], out[0][1], "phi of the slabs after three cycles")
+    assert out[1][2:4] == out[0][2:4]
+    assert_bit_equal(out[1][4], out[0][4], "phi of the slabs after the solve")
+
+
 @pytest.mark.parametrize("devices,cut", [([0, 0], 0), ([0, 0, 0], 2), ([0] * 4, 1)], ids=str)
 def test_sequence_of_warm_started_solves_on_slabs(gpu, devices, cut):
     """The reference's time loop calls solve() again and again on a changing rho with phi and the
