@@ -37,7 +37,10 @@ KERNEL_BYTES_PER_POINT = {"smooth_fine": 16.0, "residual": 24.0, "restrict": 9.0
 
 # kernel names in the profile summaries: (prefix, suffix).  The fine sweep of the timed cycle is the
 # single-pass kernel in its "correction applied while loading" form (last template argument 1).
-PROFILE_KERNEL = {"smooth_fine": ("k_sweep_rb<", ", 1>"), "residual": ("k_residual_restrict", "false>"),  # (the instance ending in true> is the Gauss-Seidel solver's norm)
+# The last template argument of the sweeps is the short-form switch (false in the timed cycle), the one
+# before it the on-load mode (1 = correction).  The residual instance ending in true> is the
+# Gauss-Seidel solver's norm.
+PROFILE_KERNEL = {"smooth_fine": ("k_sweep_rb<", ", 1, false>"), "residual": ("k_residual_restrict", "false>"),
                   "prolong_correct": ("k_prolong<true>", "")}
 
 
