@@ -306,18 +306,29 @@ __global__ __launch_bounds__(NT) void k_sweep_rb(View uin, View uout, View rhs, 
         }
     }
     if (MODE != kLoadPlain) {
-        // the three planes loaded above are needed at once: fix them plane by plane, staging the
-        // coarse planes each one needs (a barrier per step; once per workgroup)
-        double cv[CE];
+        // The three planes loaded above are needed at once: fix them plane by plane, staging the
+        // coarse planes each one needs (two barriers per step; once per workgroup).  Planes ia-2 ..
+        // ia lie between coarse planes (ia-2)>>1 and that plus two: all three are requested here,
+        // together with the loads above, so the steps below wait for memory once and not six times.
+        const int I0 = (ia - 2) >> 1;
+        double c0[CE], c1[CE], c2[CE];
+#pragma unroll
+        for (int t = 0; t < CE; t++) {
+            c0[t] = coarse_elem(I0, tid + t * NT);
+            c1[t] = coarse_elem(I0 + 1, tid + t * NT);
+            c2[t] = coarse_elem(I0 + 2, tid + t * NT);
+        }
+#pragma unroll
         for (int step = 0; step < 3; step++) {
-            const int f = ia - 2 + step, I = f >> 1;
+            const int f = ia - 2 + step, I = f >> 1;  // I - I0 is 0 or 1
             __syncthreads();
-#pragma unroll
-            for (int t = 0; t < CE; t++) cv[t] = coarse_elem(I, tid + t * NT);
-            stage_write(I, cv);
-#pragma unroll
-            for (int t = 0; t < CE; t++) cv[t] = coarse_elem(I + 1, tid + t * NT);
-            stage_write(I + 1, cv);
+            if (I == I0) {
+                stage_write(I, c0);
+                stage_write(I + 1, c1);
+            } else {
+                stage_write(I, c1);
+                stage_write(I + 1, c2);
+            }
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < Q; q++) {
