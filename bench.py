@@ -346,9 +346,10 @@ def sweep_roofline(libmg, n, planes, device):
     from multigrid_amd import problem
     pitch = (n + 1) & ~1
     dev = torch.device("cuda", device)
-    u = torch.zeros((planes + 4, n, pitch), dtype=torch.float64, device=dev)
+    # (random operands: all-zero arrays would send every quotient down the smoother's rare-operand path)
+    u = torch.rand((planes + 4, n, pitch), dtype=torch.float64, device=dev)
     alt = torch.zeros_like(u)
-    rhs = torch.zeros((planes + 2, n, pitch), dtype=torch.float64, device=dev)
+    rhs = torch.rand((planes + 2, n, pitch), dtype=torch.float64, device=dev)
     lib = libmg.load()
     N = (n, n, n)
     coef = (C.c_double * 4)()
@@ -483,7 +484,7 @@ def run_distributed(args):
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{n}^3 fp64 multigrid V{depth} cycle, red-black GS-SOR, slab-partitioned over "
                                       f"{world} GPUs (halo planes over RCCL send/recv, levels >= {cut} "
-                                      f"gathered on rank 0)", "grid": n, "depth": depth, "driver": "libmg_hip mg_dist (C++)",
+                                      f"all-gathered and solved whole on every GPU)", "grid": n, "depth": depth, "driver": "libmg_hip mg_dist (C++)",
                           "note": "N=1 runs the 513^3 headline configuration; N>=2 run 1025^3 (strong scaling among N>=2)"},
                "vcycles_per_s": vps, "last_L2": l2, "roofline": roofline, "cpu_baseline": cpu, "solve": solve,
                "single_gpu_same_workload": base1, "halo_bytes_sent_rank0": stats["bytes_sent"],
@@ -636,7 +637,7 @@ def run_distributed_python(args):
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{n}^3 fp64 multigrid V{depth} cycle, red-black GS-SOR, slab-partitioned over "
                                       f"{world} GPUs (halo planes over RCCL send/recv, levels >= {s_cut(N, depth, world)} "
-                                      f"gathered on rank 0)", "grid": n, "depth": depth,
+                                      f"all-gathered and solved whole on every GPU)", "grid": n, "depth": depth,
                           "note": "N=1 runs the 513^3 headline configuration; N>=2 run 1025^3 (strong scaling among N>=2)"},
                "vcycles_per_s": vps, "last_L2": l2, "roofline": roofline, "cpu_baseline": cpu, "solve": solve,
                "single_gpu_same_workload": base1, "halo_bytes_sent_rank0": comm.bytes_sent}
