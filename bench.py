@@ -386,8 +386,8 @@ def sweep_roofline(libmg, n, planes, device):
 
 def run_distributed(args):
     """N > 1: one rank per GPU (launched by torch.distributed.run), 1025^3 slab-partitioned, driven by
-    the C++ rank driver inside libmg_hip (mg_dist_*): halo planes, the norm all-reduce and the coarse
-    gather/scatter go over RCCL.  torch.distributed (gloo) only carries the rendezvous: the RCCL
+    the C++ rank driver inside libmg_hip (mg_dist_*): halo planes, the norm all-reduce and the
+    all-gather of the first whole level go over RCCL.  torch.distributed (gloo) only carries the rendezvous: the RCCL
     unique id, the barriers around the timed region and the max over the ranks' times."""
     import torch  # before libmg_hip: both must share one HIP runtime
     import torch.distributed as dist
