@@ -1,9 +1,10 @@
-"""Solve times on the reference's small configurations (41^3 V2, 129^3 V3, 257^3 V5) next to the CPU oracle."""
+"""Solve times on the reference's small configurations (41^3 V2, 129^3 V3, 257^3 V5), beside the time per
+cycle of bench.py's CPU baseline leg (the reference-order cycle on one host core) at the same size."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from multigrid_amd import libmg, problem
-from oracle import mg_oracle as orc
+import bench
 
 for n, depth in ((41, 2), (129, 3), (257, 5)):
     N = (n, n, n)
@@ -19,10 +20,6 @@ for n, depth in ((41, 2), (129, 3), (257, 5)):
         ok, cyc, l2 = h.solve(10000, 1e-6)
         dt = time.perf_counter() - t0
         dev = h.last_call_ms()
-    phi = np.zeros(N)
-    s = orc.Solver(N, dh, depth)
-    t0 = time.perf_counter()
-    ok2, cyc2, l22, _ = s.solve(phi, rho, 10000 if n < 257 else 5, 1e-6)
-    dtc = time.perf_counter() - t0
+    cpu = bench.cpu_baseline(n, depth, 40 if n < 100 else 3)
     print(f"{n}^3 V{depth}: GPU {cyc} cycles {dt*1e3:.2f} ms wall ({dev:.2f} ms device, {dev/cyc*1e3:.0f} us/cycle) | "
-          f"CPU lexicographic {cyc2} cycles {dtc:.3f} s ({dtc/cyc2*1e3:.2f} ms/cycle)")
+          f"CPU lexicographic {cpu['s_per_cycle']*1e3:.2f} ms/cycle")
