@@ -181,10 +181,9 @@ void sweep_rb_tile(hipStream_t s, View uin, View uout, View rhs, const int64_t n
     // alike; 40 planes of 129^2: 10.0 / 9.1 / 9.7)
     const int64_t area = uin.d[1] * uin.d[2];
     int ti = (planes <= 2 || area <= 40 * 40) ? 2 : (planes <= 4 || area <= 136 * 136) ? 4 : 8;
-    if (shape) ti = shape;
+    if (shape == 2 || shape == 4 || shape == 8) ti = shape;
     if (ti == 2) launch_tile<2>(s, uin, uout, rhs, n, c, omega, r, r2);
     else if (ti == 4) launch_tile<4>(s, uin, uout, rhs, n, c, omega, r, r2);
-    else if (ti == 12) launch_tile<12>(s, uin, uout, rhs, n, c, omega, r, r2);
     else launch_tile<8>(s, uin, uout, rhs, n, c, omega, r, r2);
 }
 
