@@ -372,6 +372,52 @@ def test_random_partitions_equal_the_undivided_handle(gpu, n, depth, world, cut,
     assert_bit_equal(got[2], want[2], "E of the slabs")
 
 
+def _cut_down_cases():
+    import os
+    g = np.random.default_rng(int(os.environ.get("MG_FUZZ_SEED", "20261111")) + 4)
+    out = []
+    for _ in range(5 * int(os.environ.get("MG_FUZZ_MULT", "1"))):
+        # a long first axis over many ranks and short sweep schedules: the ranges a rank needs of the
+        # whole levels are then well below half a level
+        n = (int(g.integers(120, 400)), int(g.integers(12, 150)), int(g.integers(12, 150)))
+        deepest = 0
+        while (min(n) >> (deepest + 1)) >= 3:
+            deepest += 1
+        depth = int(g.integers(2, min(deepest, 5) + 1)) if deepest >= 2 else deepest
+        cut = int(g.integers(1, depth + 1))
+        nu = tuple(int(x) for x in g.integers(0, 4, size=depth)) + (int(g.integers(1, 12)),)
+        out.append((n, depth, int(g.integers(4, 17)), cut, nu))
+    return out
+
+
+@pytest.mark.parametrize("n,depth,world,cut,nu", _cut_down_cases(), ids=str)
+def test_random_sweep_schedules_on_cut_down_levels(gpu, n, depth, world, cut, nu):
+    """Random grids with a long first axis, many ranks, random short sweep schedules (zero sweeps on
+    a level included) and cuts: whatever planes of the whole levels each rank decides to compute, the
+    potential equals the undivided handle's."""
+    from multigrid_amd import problem
+    if depth < 1:
+        pytest.skip("grid too small for a coarse level")
+    dh = problem.main_extents_dh(n)
+    g = np.random.default_rng(23 + sum(n))
+    rho, phi0 = g.uniform(-1, 1, n) * 8.85e-9, g.uniform(-1, 1, n)
+    try:
+        h = gpu.Handle(n, dh, depth, nu=nu, devices=[0] * world, coarse_cut=cut)
+    except gpu.MgError as e:
+        assert e.code == -1 and "planes over" in str(e)
+        return
+    with h:
+        h.set_rho(rho)
+        h.set_phi(phi0)
+        l2 = h.vcycles(3)
+        got = h.get_phi()
+    with gpu.Handle(n, dh, depth, nu=nu) as h:
+        h.set_rho(rho)
+        h.set_phi(phi0)
+        assert h.vcycles(3) == pytest.approx(l2, rel=1e-12)
+        assert_bit_equal(got, h.get_phi(), "phi of the slabs")
+
+
 def _late_exchange_cases():
     import os
     g = np.random.default_rng(int(os.environ.get("MG_FUZZ_SEED", "20261111")) + 3)
