@@ -413,7 +413,8 @@ typedef struct mg_dist_config {
     int32_t rank, world;
     int32_t coarse_cut;  /* levels >= this are held and solved whole by every rank; 0 = first level with <= 128 planes */
     int32_t transport;   /* MG_TRANSPORT_* */
-    int32_t no_overlap;  /* 1: exchange halos after whole sweeps instead of under their interior part */
+    int32_t no_overlap;  /* bit 0: exchange halos after whole sweeps instead of under their interior part;
+                            bit 1: exchange after every sweep on every level (no deep halos, see mg_dist_deep_halos) */
     uint8_t unique_id[MG_UNIQUE_ID_BYTES];  /* MG_TRANSPORT_RCCL */
     mg_local_group *local_group;            /* MG_TRANSPORT_LOCAL */
 } mg_dist_config;
@@ -428,6 +429,13 @@ int mg_dist_destroy(mg_dist *d);
 /* The rank's share: *cut, the fine planes it owns [own[0], own[1]), and the planes of phi and of
  * rho it stores and must be given (owned + halo planes). */
 int mg_dist_plan(mg_dist *d, int32_t *cut, int64_t own[2], int64_t stored_phi[2], int64_t stored_rho[2]);
+/* *deep = 1 when the levels 1..cut-1 are smoothed on deep halos: each rank receives once per cycle
+ * the planes of R_l that all sweeps of level l reach beyond its slab (two per sweep and side) and
+ * computes eps_l on them as its neighbour does, instead of exchanging two planes after every
+ * sweep.  Chosen at creation when every rank finds those planes on its two neighbours and bit 1
+ * of mg_dist_config.no_overlap is clear; the results are the same bits either way.  No counterpart
+ * in the reference. */
+int mg_dist_deep_halos(mg_dist *d, int32_t *deep);
 /* Dense host planes [lo,hi) of the global arrays, rows of nk doubles; any sub-range of the stored
  * planes, so a rank never needs its whole slab in host memory.  rho is stored as rho/EPS_0. */
 int mg_dist_set_rho_planes(mg_dist *d, int64_t lo, int64_t hi, const double *dense);

@@ -694,7 +694,7 @@ int mg_device_bytes(const mg_config *cfg, uint64_t *bytes)
         const long long n[3] = {cfg->n[0], cfg->n[1], cfg->n[2]};
         long long most = 0;
         for (int r = 0; r < cfg->n_gpus; r++) {
-            const long long b = mgk::dist_rank_device_bytes(n, L, cfg->n_gpus, cfg->coarse_cut, r);
+            const long long b = mgk::dist_rank_device_bytes(n, L, cfg->n_gpus, cfg->coarse_cut, r, cfg->nu);
             if (b < 0) return MG_ERR_INVALID;  // the plan's message stands
             if (b > most) most = b;
         }

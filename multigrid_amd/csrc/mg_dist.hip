@@ -17,6 +17,12 @@
 //     neighbour, (2) start of the exchange of exactly those planes on the communication stream,
 //     (3) the interior -- which reads no halo plane of the previous sweep -- and the next reader
 //     of the halos waits for the transfer.  The fine residual+restriction is split the same way;
+//   * deep halos on the coarse distributed levels: where every rank finds them on its two
+//     neighbours, a rank receives ONCE per cycle as many planes of R_l as all nu_l sweeps of level l
+//     reach (2 per sweep), forms eps_l on its slab widened by that much and sweeps ranges that
+//     shrink by two planes per side and sweep -- no exchange between the sweeps, no separate
+//     launches for the planes next to a neighbour, two sweeps per launch where the kernels offer
+//     it.  The planes computed twice (here and on the neighbour) get the same bits on both;
 //   * the sum of squared residuals is all-reduced once per cycle, beside the kernels: nothing on the
 //     kernel stream waits for it but the next writer of the sum and the host's read of it;
 //   * R of level `cut` is all-gathered and EVERY rank solves level `cut` and everything below it on
@@ -127,6 +133,13 @@ const Rccl *rccl()
 
 // ---------------------------------------------------------------------------- plan
 
+constexpr int H_U = 2, H_RHS = 1;  // halo planes of swept fields / of right-hand sides
+
+inline IRange widen(IRange r, int64_t by, int64_t top)
+{
+    return IRange{r.lo - by < 0 ? 0 : r.lo - by, r.hi + by > top ? top : r.hi + by};
+}
+
 // Who owns which planes of which level.  Pure arithmetic.
 struct Plan {
     int64_t n0[3];
@@ -190,9 +203,59 @@ struct Plan {
         const int64_t top = planes(l, eps);
         return IRange{o.lo - halo < 0 ? 0 : o.lo - halo, o.hi + halo > top ? top : o.hi + halo};
     }
+
+    // Deep halos.  Planes of eps_l (levels 1..cut-1) a rank must hold after the level's last sweep
+    // (`last`: what the level above forms its own planes from) and forms by prolongation before the
+    // first (`first`): a sweep needs its input two planes further out on either side than it
+    // produces, so sweep s of nu produces `last` widened by 2*(nu-s) and the prolongation before the
+    // first sweep covers `last` widened by 2*nu.  The level below is needed on the planes that
+    // prolongation reads: fine planes [lo, hi) read coarse planes lo/2 .. hi/2.
+    void deep_ranges(int rank, const int *nu, IRange *last, IRange *first) const
+    {
+        IRange need = stored(0, false, rank, H_U);  // fine planes the correction phi -= P(eps_1) reaches
+        for (int l = 1; l < cut; l++) {
+            const int64_t top = planes(l, true);
+            last[l] = IRange{need.lo >> 1, (need.hi >> 1) + 1 > top ? top : (need.hi >> 1) + 1};
+            first[l] = widen(last[l], 2 * (int64_t)nu[l], top);
+            need = first[l];
+        }
+    }
+    // the planes of R_l a rank smooths against in that scheme: those of eps_l, as far as R_l has them
+    IRange deep_rhs(int l, IRange first) const
+    {
+        const int64_t top = planes(l, false);
+        return IRange{first.lo, first.hi > top ? top : first.hi};
+    }
+    // Deep halos are used when every rank finds the planes beyond its own on its two neighbours (one
+    // message per side and level).
+    bool deep_fits(const int *nu) const
+    {
+        if (world < 2 || cut < 2) return false;
+        for (int l = 1; l < cut; l++)
+            if (nu[l] > 4096) return false;
+        for (int r = 0; r < world; r++) {
+            IRange last[MG_MAX_LEVELS], first[MG_MAX_LEVELS];
+            deep_ranges(r, nu, last, first);
+            for (int l = 1; l < cut; l++) {
+                const int64_t lo = r > 0 ? own(l, true, r - 1).lo : 0;
+                const int64_t hi = r + 1 < world ? own(l, true, r + 1).hi : planes(l, true);
+                if (first[l].lo < lo || first[l].hi > hi) return false;
+            }
+        }
+        return true;
+    }
 };
 
 // ---------------------------------------------------------------------------- storage
+
+// Planes exchanged with the slab neighbours around an owned range [lo, hi): received into
+// [lo - rlo, lo) and [hi, hi + rhi), sent from [lo, lo + slo) to the rank below and from
+// [hi - shi, hi) to the rank above.  What a rank sends is what its neighbour receives; the sides
+// without a neighbour are ignored.
+struct Halo {
+    int rlo, slo, shi, rhi;
+    static Halo both(int w) { return Halo{w, w, w, w}; }
+};
 
 // Planes [v.i0, v.i0 + v.d[0]) of a level's array on this rank's GPU.
 struct Slab {
@@ -201,7 +264,7 @@ struct Slab {
     bool pending = false;
     hipEvent_t done = nullptr;  // RCCL transport: recorded on the communication stream
     IRange held_own{0, 0};      // in-process transport holding the exchange back: what to do at the wait
-    int held_width = 0;
+    Halo held{0, 0, 0, 0};
 
     double *plane(int64_t i) const { return v.p + (i - v.i0) * v.si; }
     size_t plane_bytes() const { return (size_t)v.si * sizeof(double); }
@@ -224,10 +287,10 @@ struct Transport {
         if (aborted.load()) return mgk::set_error(MG_ERR_COMM, "the group was given up after a rank failed");
         return MG_OK;
     }
-    // Exchange `width` halo planes per side of `s` around the owned range `own` with the slab
-    // neighbours; ordered after everything enqueued on `compute` so far.  finish() makes
-    // `compute` wait for it.
-    virtual int start(Slab &s, IRange own, int width, hipStream_t compute) = 0;
+    // Exchange the halo planes `h` of `s` around the owned range `own` with the slab neighbours;
+    // ordered after everything enqueued on `compute` so far.  finish() makes `compute` wait for it.
+    virtual int start(Slab &s, IRange own, Halo h, hipStream_t compute) = 0;
+    int start(Slab &s, IRange own, int width, hipStream_t compute) { return start(s, own, Halo::both(width), compute); }
     virtual int finish(Slab &s, hipStream_t compute) = 0;
     // *dev_scalar = sum over ranks, same bits on every rank; ordered after everything enqueued on
     // `compute` so far.  `compute` itself does not wait: sum_ready() makes it, and must precede the
@@ -341,24 +404,25 @@ struct RcclTransport : Transport {
         HIP_TRY(hipStreamWaitEvent(compute, from_cs, 0));
         return MG_OK;
     }
-    int start(Slab &s, IRange own, int w, hipStream_t compute) override
+    int start(Slab &s, IRange own, Halo h, hipStream_t compute) override
     {
         TRY(alive());
         TRY(finish(s, compute));
         if (world == 1) return MG_OK;
         if (!s.done) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         TRY(order_after_compute(compute));
-        const size_t count = (size_t)w * (size_t)s.v.si;
+        const size_t plane = (size_t)s.v.si;
+        // (a side with nothing to move is left out on both ranks: this rank's count is its neighbour's)
         NCCL_TRY(api->GroupStart());
         if (rank + 1 < world) {
-            NCCL_TRY(api->Send(s.plane(own.hi - w), count, ncclDouble, rank + 1, comm, cs));
-            NCCL_TRY(api->Recv(s.plane(own.hi), count, ncclDouble, rank + 1, comm, cs));
-            bytes_sent += count * 8;
+            if (h.shi > 0) NCCL_TRY(api->Send(s.plane(own.hi - h.shi), h.shi * plane, ncclDouble, rank + 1, comm, cs));
+            if (h.rhi > 0) NCCL_TRY(api->Recv(s.plane(own.hi), h.rhi * plane, ncclDouble, rank + 1, comm, cs));
+            bytes_sent += h.shi * plane * 8;
         }
         if (rank > 0) {
-            NCCL_TRY(api->Send(s.plane(own.lo), count, ncclDouble, rank - 1, comm, cs));
-            NCCL_TRY(api->Recv(s.plane(own.lo - w), count, ncclDouble, rank - 1, comm, cs));
-            bytes_sent += count * 8;
+            if (h.slo > 0) NCCL_TRY(api->Send(s.plane(own.lo), h.slo * plane, ncclDouble, rank - 1, comm, cs));
+            if (h.rlo > 0) NCCL_TRY(api->Recv(s.plane(own.lo - h.rlo), h.rlo * plane, ncclDouble, rank - 1, comm, cs));
+            bytes_sent += h.slo * plane * 8;
         }
         NCCL_TRY(api->GroupEnd());
         HIP_TRY(hipEventRecord(s.done, cs));
@@ -475,39 +539,39 @@ struct LocalTransport : Transport {
         if (rc) g->abandon();
         return rc;
     }
-    int exchange_now(Slab &s, IRange own, int w, hipStream_t compute)
+    int exchange_now(Slab &s, IRange own, Halo h, hipStream_t compute)
     {
         HIP_TRY(hipStreamSynchronize(compute));
         g->post[rank] = &s.v;
         TRY(meet());
         if (rank + 1 < world) {
-            TRY(copy_planes(s, *g->post[rank + 1], IRange{own.hi, own.hi + w}, compute));
-            bytes_sent += (uint64_t)w * s.v.si * 8;
+            TRY(copy_planes(s, *g->post[rank + 1], IRange{own.hi, own.hi + h.rhi}, compute));
+            bytes_sent += (uint64_t)h.shi * s.v.si * 8;
         }
         if (rank > 0) {
-            TRY(copy_planes(s, *g->post[rank - 1], IRange{own.lo - w, own.lo}, compute));
-            bytes_sent += (uint64_t)w * s.v.si * 8;
+            TRY(copy_planes(s, *g->post[rank - 1], IRange{own.lo - h.rlo, own.lo}, compute));
+            bytes_sent += (uint64_t)h.slo * s.v.si * 8;
         }
         HIP_TRY(hipStreamSynchronize(compute));
         return meet();  // nobody overwrites what a neighbour is still copying
     }
-    int start(Slab &s, IRange own, int w, hipStream_t compute) override
+    int start(Slab &s, IRange own, Halo h, hipStream_t compute) override
     {
         TRY(finish(s, compute));
         if (world == 1) return MG_OK;
         if (g->hold_back) {
             s.pending = true;
             s.held_own = own;
-            s.held_width = w;
+            s.held = h;
             return MG_OK;
         }
-        return guard(exchange_now(s, own, w, compute));
+        return guard(exchange_now(s, own, h, compute));
     }
     int finish(Slab &s, hipStream_t compute) override
     {
         if (!s.pending) return MG_OK;
         s.pending = false;
-        return guard(exchange_now(s, s.held_own, s.held_width, compute));
+        return guard(exchange_now(s, s.held_own, s.held, compute));
     }
     int allreduce_now(double *x, hipStream_t compute)
     {
@@ -554,7 +618,7 @@ struct LocalTransport : Transport {
 // in the full world; halo planes keep whatever they hold and the sums stay local, so the numbers
 // a solve produces mean nothing.
 struct SoloTransport : Transport {
-    int start(Slab &, IRange, int, hipStream_t) override { return MG_OK; }
+    int start(Slab &, IRange, Halo, hipStream_t) override { return MG_OK; }
     int finish(Slab &, hipStream_t) override { return MG_OK; }
     int allreduce(double *, hipStream_t) override { return MG_OK; }
     int sum_ready(hipStream_t) override { return MG_OK; }
@@ -564,8 +628,6 @@ struct SoloTransport : Transport {
     }
 };
 
-constexpr int H_U = 2, H_RHS = 1;  // halo planes of swept fields / of right-hand sides
-
 }  // namespace
 
 // ---------------------------------------------------------------------------- one rank
@@ -574,6 +636,11 @@ struct mg_dist {
     Plan plan;
     int rank = 0, world = 1, L = 0, cut = 0, device = 0;
     bool overlap = true;
+    // deep halos on levels 1..cut-1 (see Plan::deep_ranges): planes of eps_l held after the last
+    // sweep / formed before the first, and the planes of R_l moved once per cycle for them
+    bool deep = false;
+    IRange dlast[MG_MAX_LEVELS], dfirst[MG_MAX_LEVELS];
+    Halo dhalo[MG_MAX_LEVELS];
     int nu[MG_MAX_LEVELS] = {};
     Coef c[MG_MAX_LEVELS];
     double omega = 1.4;
@@ -711,6 +778,45 @@ struct mg_dist {
         return MG_OK;
     }
 
+    // The nu[l] sweeps of a distributed level on deep halos: eps_l = P(eps_{l+1}) on dfirst[l], then
+    // sweep s on dlast[l] widened by 2*(nu-s) planes per side.  No exchange: the planes beyond the
+    // owned ones are computed here as the neighbour computes them, from R_l planes received once.
+    int sweeps_deep(int l, Slab &below)
+    {
+        int64_t n[3];
+        plan.level_n(l, n);
+        const int64_t top = plan.planes(l, true);
+        Slab &u = eps[l], &alt = eps_alt[l];
+        const Slab &rhs = R[l];
+        TRY(tr->finish(below, stream));
+        TRY(tr->finish(R[l], stream));
+        const auto out = [&](int s) { return widen(dlast[l], 2 * (int64_t)(nu[l] - s), top); };
+        int s = 1;
+        if (nu[l] > 0 && alt.v.p && mgk::onload_folds(u.v, false)) {
+            const int rc = run_sweep(u, alt, rhs, &below, false, n, l, out(1), IRange{0, 0});
+            if (rc < 0) return rc;
+            if (rc != 1) FAIL(MG_ERR_STATE, "out-of-place sweep expected");
+            std::swap(u, alt);
+            s = 2;
+        } else {
+            mgk::prolong(stream, below.v, u.v, n, IRange{dfirst[l].lo, dfirst[l].hi > n[0] ? n[0] : dfirst[l].hi});
+        }
+        while (s <= nu[l]) {
+            View vu = u.v, va = alt.v;
+            const double *before = vu.p;
+            if (s + 1 <= nu[l] && mgk::sweeps_in_pairs(vu, va, rhs.v, n, out(s + 1))) {
+                mgk::smooth_rb(stream, &vu, &va, rhs.v, n, c[l], omega, 2, out(s + 1));
+                s += 2;
+            } else {
+                mgk::smooth_rb(stream, &vu, &va, rhs.v, n, c[l], omega, 1, out(s));
+                s += 1;
+            }
+            if (vu.p != before) std::swap(u, alt);
+        }
+        HIP_TRY(hipGetLastError());
+        return MG_OK;
+    }
+
     // phi -= P(eps_1) of the last iteration, if it still waits for the next fine sweep
     int flush_correction()
     {
@@ -789,11 +895,9 @@ struct mg_dist {
             plan.level_n(l, n);
             mgk::restrict27(stream, cR[l].v, cR[l + 1].v, n, IRange{0, plan.planes(l + 1, false)});
         }
-        const auto widen = [](IRange r, int64_t by, int64_t top) {
-            return IRange{r.lo - by < 0 ? 0 : r.lo - by, r.hi + by > top ? top : r.hi + by};
-        };
         IRange last[MG_MAX_LEVELS], first[MG_MAX_LEVELS];  // planes of eps_l after its last sweep / before its first
-        IRange need = plan.stored(cut - 1, cut > 1, rank, H_U);  // planes of level cut-1 formed from eps_cut
+        // planes of level cut-1 formed from eps_cut
+        IRange need = deep ? dfirst[cut - 1] : plan.stored(cut - 1, cut > 1, rank, H_U);
         for (int l = cut; l <= L; l++) {
             const int64_t top = plan.planes(l, true);
             // the prolongation onto fine planes [lo, hi) reads coarse planes lo/2 .. hi/2
@@ -830,7 +934,8 @@ struct mg_dist {
             // R_l's halo plane below feeds the restriction; both feed the sweeps' red halo planes
             plan.level_n(l, n);
             const IRange oc = own(l + 1, false);
-            TRY(tr->start(R[l], own(l, false), H_RHS, stream));
+            // (with deep halos the plane above the slab comes later, with the others the sweeps reach)
+            TRY(tr->start(R[l], own(l, false), deep ? Halo{H_RHS, 0, H_RHS, 0} : Halo::both(H_RHS), stream));
             if (world > 1 && overlap && rank > 0 && oc.hi - oc.lo >= 2) {
                 // only the first coarse plane reads the halo plane: the others go first, under the exchange
                 mgk::restrict27(stream, R[l].v, R[l + 1].v, n, IRange{oc.lo + 1, oc.hi});
@@ -843,6 +948,16 @@ struct mg_dist {
         }
         HIP_TRY(hipGetLastError());
         TRY(tr->allgather(plan, cut, false, R[cut], cR[cut], stream));
+        if (deep) {
+            // the planes of R_l the sweeps of level l reach beyond the owned ones: one message per
+            // side and level, queued behind the all-gather (which the whole levels wait for) and in
+            // the order they are needed; they travel while the whole levels are solved
+            for (int l = cut - 1; l >= 1; l--) TRY(tr->start(R[l], own(l, false), dhalo[l], stream));
+            TRY(coarse_levels());
+            for (int l = cut - 1; l >= 1; l--) TRY(sweeps_deep(l, eps_of(l + 1)));
+            correction_pending = true;
+            return MG_OK;
+        }
         TRY(coarse_levels());
         for (int l = cut - 1; l >= 1; l--) {
             Slab &below = eps_of(l + 1);
@@ -914,11 +1029,15 @@ int upload_planes(mg_dist *d, Slab &dst, int64_t lo, int64_t hi, const double *d
 }  // namespace
 
 // The allocations of mg_dist_create for one rank, as arithmetic (keep the two lists alike).
-long long mgk::dist_rank_device_bytes(const long long n_[3], int depth, int world, int coarse_cut, int rank)
+long long mgk::dist_rank_device_bytes(const long long n_[3], int depth, int world, int coarse_cut, int rank,
+                                      const int *nu)
 {
     const int64_t n[3] = {n_[0], n_[1], n_[2]};
     Plan P;
     if (P.init(n, depth, world, coarse_cut)) return -1;
+    IRange dlast[MG_MAX_LEVELS], dfirst[MG_MAX_LEVELS];
+    const bool deep = P.deep_fits(nu);
+    if (deep) P.deep_ranges(rank, nu, dlast, dfirst);
     auto bytes = [&](int l, bool eps_kind, IRange st) -> long long {
         int64_t d[3];
         P.dims(l, eps_kind, d);
@@ -926,8 +1045,9 @@ long long mgk::dist_rank_device_bytes(const long long n_[3], int depth, int worl
     };
     long long sum = 2 * bytes(0, false, P.stored(0, false, rank, H_U)) + bytes(0, false, P.stored(0, false, rank, H_RHS));
     for (int l = 1; l <= P.cut; l++) {
-        sum += bytes(l, false, P.stored(l, false, rank, H_RHS));
-        if (l < P.cut) sum += 2 * bytes(l, true, P.stored(l, true, rank, H_U));
+        const bool wide = deep && l < P.cut;
+        sum += bytes(l, false, wide ? P.deep_rhs(l, dfirst[l]) : P.stored(l, false, rank, H_RHS));
+        if (l < P.cut) sum += 2 * bytes(l, true, wide ? dfirst[l] : P.stored(l, true, rank, H_U));
     }
     for (int l = P.cut; l <= depth; l++)
         sum += bytes(l, false, IRange{0, P.planes(l, false)}) + 2 * bytes(l, true, IRange{0, P.planes(l, true)});
@@ -1035,9 +1155,29 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
     d->device = base.device;
     d->L = base.depth;
     d->omega = base.omega;
-    d->overlap = cfg->no_overlap == 0;
+    d->overlap = (cfg->no_overlap & 1) == 0;
     CREATE_TRY(d->plan.init(base.n, base.depth, cfg->world, cfg->coarse_cut));
     d->cut = d->plan.cut;
+    d->deep = (cfg->no_overlap & 2) == 0 && d->plan.deep_fits(base.nu);
+    if (d->deep) {
+        const Plan &P = d->plan;
+        P.deep_ranges(cfg->rank, base.nu, d->dlast, d->dfirst);
+        // what this rank receives is what its ranges reach beyond the owned planes; what it sends is
+        // what its neighbours' ranges reach into them
+        IRange lastn[MG_MAX_LEVELS], below[MG_MAX_LEVELS], above[MG_MAX_LEVELS];
+        if (cfg->rank > 0) P.deep_ranges(cfg->rank - 1, base.nu, lastn, below);
+        if (cfg->rank + 1 < cfg->world) P.deep_ranges(cfg->rank + 1, base.nu, lastn, above);
+        for (int l = 1; l < d->cut; l++) {
+            const IRange o = P.own(l, false, cfg->rank), f = P.deep_rhs(l, d->dfirst[l]);
+            Halo h{(int)(o.lo - f.lo), 0, 0, (int)(f.hi > o.hi ? f.hi - o.hi : 0)};
+            if (cfg->rank > 0) {
+                const IRange fb = P.deep_rhs(l, below[l]);
+                h.slo = (int)(fb.hi > o.lo ? fb.hi - o.lo : 0);
+            }
+            if (cfg->rank + 1 < cfg->world) h.shi = (int)(o.hi - P.deep_rhs(l, above[l]).lo);
+            d->dhalo[l] = h;
+        }
+    }
     d->n_nodes = (double)base.n[0] * (double)base.n[1] * (double)base.n[2];
     for (int a = 0; a < 3; a++) d->dh[a] = base.dh[a];
     for (int l = 0; l <= d->L; l++) {
@@ -1086,10 +1226,11 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
     CREATE_TRY(d->alloc(&d->phi_alt, 0, false, P.stored(0, false, r, H_U)));
     CREATE_TRY(d->alloc(&d->b, 0, false, P.stored(0, false, r, H_RHS)));
     for (int l = 1; l <= d->cut; l++) {
-        CREATE_TRY(d->alloc(&d->R[l], l, false, P.stored(l, false, r, H_RHS)));
+        const bool wide = d->deep && l < d->cut;
+        CREATE_TRY(d->alloc(&d->R[l], l, false, wide ? P.deep_rhs(l, d->dfirst[l]) : P.stored(l, false, r, H_RHS)));
         if (l < d->cut) {
-            CREATE_TRY(d->alloc(&d->eps[l], l, true, P.stored(l, true, r, H_U)));
-            CREATE_TRY(d->alloc(&d->eps_alt[l], l, true, P.stored(l, true, r, H_U)));
+            CREATE_TRY(d->alloc(&d->eps[l], l, true, wide ? d->dfirst[l] : P.stored(l, true, r, H_U)));
+            CREATE_TRY(d->alloc(&d->eps_alt[l], l, true, wide ? d->dfirst[l] : P.stored(l, true, r, H_U)));
         }
     }
     for (int l = d->cut; l <= d->L; l++) {
@@ -1127,6 +1268,13 @@ int mg_dist_plan(mg_dist *d, int32_t *cut, int64_t own[2], int64_t stored_phi[2]
     if (own) { own[0] = o.lo; own[1] = o.hi; }
     if (stored_phi) { stored_phi[0] = d->phi.v.i0; stored_phi[1] = d->phi.v.i_end(); }
     if (stored_rho) { stored_rho[0] = d->b.v.i0; stored_rho[1] = d->b.v.i_end(); }
+    return MG_OK;
+}
+
+int mg_dist_deep_halos(mg_dist *d, int32_t *deep)
+{
+    if (!d || !deep) FAIL(MG_ERR_INVALID, "null argument");
+    *deep = d->deep ? 1 : 0;
     return MG_OK;
 }
 

@@ -241,6 +241,10 @@ int prolong_smooth_rb(hipStream_t s, View ec, bool correct, View *u, View *alt, 
 // r2: second plane range for the same (single, out-of-place) sweep; see sweep_rb_fused.
 int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c, double omega,
               int sweeps, IRange r, IRange r2 = IRange{0, 0});
+// Whether smooth_rb does two sweeps on planes r in ONE launch (reading planes r.lo-4 .. r.hi+3 of
+// *u): a caller that narrows the range from sweep to sweep may only hand over two sweeps at once
+// when this holds -- otherwise they would run one after the other, both on r.
+bool sweeps_in_pairs(const View &u, const View &alt, const View &rhs, const int64_t n[3], IRange r);
 
 // R = A*phi - b inside, R = phi on the faces of the n-sized level, for planes r; per-workgroup
 // sums of squares go to partials[0..residual_partials(n, r)).

@@ -484,6 +484,18 @@ static bool use_tile_sweep() { static const int v = exp_knob("MG_EXP_NO_TILE", 0
 
 bool sweep_is_out_of_place(const View &u) { return use_fused_sweep(u) || (use_tile_sweep() && u.d[0] >= 1); }
 
+bool sweeps_in_pairs(const View &u, const View &alt, const View &rhs, const int64_t n[3], IRange r)
+{
+    const bool tile = alt.p && use_tile_sweep() && (!use_fused_sweep(u) || r.hi - r.lo <= tile_max_planes(u));
+    const bool fused = !tile && alt.p && use_fused_sweep(u);
+    // two sweeps per launch where the stored planes reach four beyond the range (always, for a
+    // whole array; a slab with two halo planes exchanges between sweeps instead)
+    const auto holds = [&](const View &v, int64_t lo, int64_t hi, int64_t top) {
+        return v.i0 <= (lo < 0 ? 0 : lo) && v.i_end() >= (hi > top ? top : hi);
+    };
+    return fused && holds(u, r.lo - 4, r.hi + 4, n[0]) && holds(rhs, r.lo - 3, r.hi + 3, n[0] - 1);
+}
+
 int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c,
               double omega, int sweeps, IRange r, IRange r2)
 {
@@ -526,12 +538,7 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
     }
     const bool tile = alt && alt->p && use_tile_sweep() && (!use_fused_sweep(*u) || r.hi - r.lo <= tile_max_planes(*u));
     const bool fused = !tile && alt && alt->p && use_fused_sweep(*u);
-    // two sweeps per launch where the stored planes reach four beyond the range (always, for a
-    // whole array; a slab with two halo planes exchanges between sweeps instead)
-    const auto holds = [&](const View &v, int64_t lo, int64_t hi, int64_t top) {
-        return v.i0 <= (lo < 0 ? 0 : lo) && v.i_end() >= (hi > top ? top : hi);
-    };
-    const bool pairs = fused && !pair && holds(*u, r.lo - 4, r.hi + 4, n[0]) && holds(rhs, r.lo - 3, r.hi + 3, n[0] - 1);
+    const bool pairs = !pair && alt && sweeps_in_pairs(*u, *alt, rhs, n, r);
     int launches = 0;
     for (int sw = 0; sw < sweeps; sw++) {
         launches++;

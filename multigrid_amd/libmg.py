@@ -146,6 +146,7 @@ SYMBOLS = {
     "mg_dist_sync": (C.c_int, [C.c_void_p]),
     "mg_dist_abort": (C.c_int, [C.c_void_p]),
     "mg_dist_stats": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_uint64)]),
+    "mg_dist_deep_halos": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
 }
 
 _lib = None
@@ -470,7 +471,7 @@ class DistRank:
     same arguments apart from rank and device; creation, vcycles, solve and close are collective."""
 
     def __init__(self, n, dh, depth, rank, world, device=0, unique_id=None, local_group=None, coarse_cut=0,
-                 nu=None, omega=None, overlap=True, alone=False, flags=0):
+                 nu=None, omega=None, overlap=True, alone=False, flags=0, deep_halos=True):
         self.n = tuple(int(a) for a in n)
         dc = MgDistConfig()
         dc.base = default_config(self.n, dh, depth, device)
@@ -480,7 +481,9 @@ class DistRank:
                 dc.base.nu[l] = v
         if omega is not None:
             dc.base.omega = omega
-        dc.rank, dc.world, dc.coarse_cut, dc.no_overlap = rank, world, coarse_cut, int(not overlap)
+        # no_overlap: bit 0 = halo exchanges after whole sweeps, bit 1 = an exchange after every sweep
+        # on every level (no deep halos)
+        dc.rank, dc.world, dc.coarse_cut, dc.no_overlap = rank, world, coarse_cut, int(not overlap) | (0 if deep_halos else 2)
         if alone:
             dc.transport = MG_TRANSPORT_NONE  # this rank of `world`, without peers: timing only
         elif local_group is not None or (world == 1 and unique_id is None):
@@ -497,6 +500,9 @@ class DistRank:
         own, sp, sr = (C.c_int64 * 2)(), (C.c_int64 * 2)(), (C.c_int64 * 2)()
         _check(load().mg_dist_plan(self._d, C.byref(cut), own, sp, sr))
         self.cut, self.own, self.stored_phi, self.stored_rho = cut.value, tuple(own), tuple(sp), tuple(sr)
+        deep = C.c_int32(0)
+        _check(load().mg_dist_deep_halos(self._d, C.byref(deep)))
+        self.deep_halos = bool(deep.value)
 
     def close(self):
         if getattr(self, "_d", None):

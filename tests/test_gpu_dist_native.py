@@ -14,7 +14,7 @@ from util import assert_bit_equal
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(gpu, world, n, depth, cut, body, hold_back=False, overlap=True, join_timeout=240):
+def run_ranks(gpu, world, n, depth, cut, body, hold_back=False, overlap=True, join_timeout=240, deep_halos=True):
     """body(rank_object, rank) on `world` threads; returns their results by rank."""
     from multigrid_amd import problem
     N = (n, n, n) if isinstance(n, int) else tuple(n)
@@ -25,7 +25,8 @@ def run_ranks(gpu, world, n, depth, cut, body, hold_back=False, overlap=True, jo
     def work(r):
         d = None
         try:
-            d = gpu.DistRank(N, dh, depth, r, world, device=0, local_group=group, coarse_cut=cut, overlap=overlap)
+            d = gpu.DistRank(N, dh, depth, r, world, device=0, local_group=group, coarse_cut=cut, overlap=overlap,
+                             deep_halos=deep_halos)
             d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
             d.set_phi(lambda lo, hi: np.zeros((hi - lo,) + N[1:]))
             out[r] = body(d, r)

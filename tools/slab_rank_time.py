@@ -97,18 +97,19 @@ def measure(n, world, rank, cycles=10, overlap=True, cut=None):
     return out
 
 
-def measure_cxx(n, world, rank, cycles=10, overlap=True, cut=None, flags=0):
+def measure_cxx(n, world, rank, cycles=10, overlap=True, cut=None, flags=0, deep_halos=True):
     """The same share driven by mg_dist (the product's driver): device time of `cycles` cycles."""
     from multigrid_amd import libmg
     N = (n, n, n)
     depth = problem.reference_depth_for(N)
     d = libmg.DistRank(N, problem.main_extents_dh(N), depth, rank, world, device=0, coarse_cut=cut or 0,
-                       overlap=overlap, alone=True, flags=flags)
+                       overlap=overlap, alone=True, flags=flags, deep_halos=deep_halos)
     d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
     d.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
     d.vcycles(2)
     d.vcycles(cycles)
-    out = {"world": world, "rank": rank, "planes": d.own, "cut": d.cut, "cycle_ms": d.stats()["last_ms"] / cycles}
+    out = {"world": world, "rank": rank, "planes": d.own, "cut": d.cut, "deep_halos": d.deep_halos,
+           "cycle_ms": d.stats()["last_ms"] / cycles}
     d.close()
     return out
 
@@ -121,6 +122,7 @@ def main():
     ap.add_argument("--cut", type=int, default=None, help="first level solved whole on rank 0 (default: first with <= 128 planes)")
     ap.add_argument("--python", action="store_true", help="time the Python twin of the schedule, level by level")
     ap.add_argument("--fast", action="store_true", help="MG_FLAG_FAST_SMOOTHER (C++ driver only)")
+    ap.add_argument("--no-deep", action="store_true", help="an exchange after every sweep on every level (C++ driver only)")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     for case in args.cases.split(","):
@@ -130,7 +132,7 @@ def main():
         else:
             from multigrid_amd import libmg
             res = measure_cxx(args.size, w, r, overlap=not args.no_overlap, cut=args.cut,
-                              flags=libmg.MG_FLAG_FAST_SMOOTHER if args.fast else 0)
+                              flags=libmg.MG_FLAG_FAST_SMOOTHER if args.fast else 0, deep_halos=not args.no_deep)
         print(" ".join(f"{k}={v:.3f}" if isinstance(v, float) else f"{k}={v}" for k, v in res.items()), flush=True)
 
 
