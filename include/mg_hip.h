@@ -379,6 +379,12 @@ int mg_dev_prolong_smooth_rb(void *stream, const mg_dev_array *ec, int correct, 
  * overlapping read neighbourhoods); 0 when it applies the operation to u in place first.  The
  * ptr member is not read. */
 int mg_dev_onload_folds(const mg_dev_array *u, int correct);
+/* 1 when mg_dev_smooth_rb with sweeps == 2 on planes [lo,hi) of arrays of these shapes does both
+ * sweeps in ONE launch, reading planes [lo-4, hi+4) of u and [lo-3, hi+3) of rhs as far as the
+ * level has them (they must be stored); otherwise the two sweeps run one after the other, both on
+ * [lo,hi).  A caller that narrows its plane range from sweep to sweep may hand over two sweeps at
+ * once only when this holds.  The ptr members are not read.  No counterpart in the reference. */
+int mg_dev_sweeps_in_pairs(const mg_dev_array *u, const mg_dev_array *rhs, const int64_t n[3], int64_t lo, int64_t hi);
 /* Planes [lo,hi) of E = -grad(phi) (cpp/PotentialSolver.cpp:418-458).  ef is a dense device
  * array [plane][nj][nk][3] whose plane 0 is global plane ef_i0 (no row padding).  Reads phi
  * planes [lo-1, hi+1), plus plane 2 when lo == 0 and plane n-3 when hi == n. */

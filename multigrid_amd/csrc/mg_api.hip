@@ -1437,6 +1437,16 @@ int mg_dev_sweep_out_of_place(const mg_dev_array *u)
     return mgk::sweep_is_out_of_place(vu) ? 1 : 0;
 }
 
+int mg_dev_sweeps_in_pairs(const mg_dev_array *u, const mg_dev_array *rhs, const int64_t n[3], int64_t lo, int64_t hi)
+{
+    View vu, vr;
+    if (!n || dev_view(u, &vu, "mg_dev_sweeps_in_pairs(u)", true) || dev_view(rhs, &vr, "mg_dev_sweeps_in_pairs(rhs)", true))
+        return 0;
+    View va = vu;
+    va.p = vu.p ? vu.p : reinterpret_cast<double *>(sizeof(double));  // "a twin array exists"; never dereferenced
+    return mgk::sweeps_in_pairs(vu, va, vr, n, IRange{lo, hi}) ? 1 : 0;
+}
+
 int mg_dev_onload_folds(const mg_dev_array *u, int correct)
 {
     View vu;

@@ -16,6 +16,10 @@ bit-identical to the undivided red-black cycle:
     planes next to each neighbour first, then the exchange of exactly those planes is started,
     then the interior -- which needs no halo plane of the previous sweep either -- so the
     exchange runs under the interior sweep; the fine residual is split the same way;
+  * deep halos on the coarse distributed levels: where every rank finds them on its two
+    neighbours, a rank receives once per cycle as many planes of R_l as all nu_l sweeps of level l
+    reach (two per sweep), forms eps_l on its slab widened by that much and sweeps ranges that
+    shrink by two planes per side and sweep, with no exchange between the sweeps;
   * the sum of squared residuals is all-reduced once per cycle;
   * R of level `cut` is all-gathered and every rank solves level `cut` and everything below it
     on whole arrays of its own (those levels are serial work of the cycle whoever runs them);
@@ -89,6 +93,38 @@ class SlabPlan:
         """Planes [lo, hi) a rank stores: owned plus `halo` planes per side, clipped to the array."""
         lo, hi = self.own(l, kind, rank)
         return max(lo - halo, 0), min(hi + halo, self.planes(l, kind))
+
+    # -- deep halos (as Plan::deep_ranges / deep_fits in csrc/mg_dist.hip)
+    def deep_ranges(self, rank, nu, halo=2):
+        """Per level l in 1..cut-1: (first, last) = the planes of eps_l a rank forms by prolongation
+        before the level's first sweep and must hold after its last.  A sweep needs its input two
+        planes further out on either side than it produces, so sweep s of nu produces `last` widened
+        by 2*(nu-s); the level below is needed on the planes the prolongation onto `first` reads."""
+        need = self.stored(0, "phi", rank, halo)  # fine planes the correction phi -= P(eps_1) reaches
+        first, last = {}, {}
+        for l in range(1, self.cut):
+            top = self.planes(l, "eps")
+            last[l] = (need[0] >> 1, min((need[1] >> 1) + 1, top))
+            first[l] = (max(last[l][0] - 2 * nu[l], 0), min(last[l][1] + 2 * nu[l], top))
+            need = first[l]
+        return first, last
+
+    def deep_rhs(self, l, first):
+        """The planes of R_l the sweeps on `first` read: those of eps_l, as far as R_l has them."""
+        return first[0], min(first[1], self.planes(l, "R"))
+
+    def deep_fits(self, nu):
+        """Deep halos are used when every rank finds the planes beyond its own on its two neighbours."""
+        if self.world < 2 or self.cut < 2 or any(nu[l] > 4096 for l in range(1, self.cut)):
+            return False
+        for r in range(self.world):
+            first, _ = self.deep_ranges(r, nu)
+            for l in range(1, self.cut):
+                lo = self.own(l, "eps", r - 1)[0] if r > 0 else 0
+                hi = self.own(l, "eps", r + 1)[1] if r + 1 < self.world else self.planes(l, "eps")
+                if first[l][0] < lo or first[l][1] > hi:
+                    return False
+        return True
 
 
 # --------------------------------------------------------------------------- storage
@@ -174,6 +210,12 @@ class HipOps:
     def onload_folds(self, u, correct):
         """True when prolong_smooth leaves u untouched (the operation rides on the sweep's loads)."""
         return bool(self.lib.mg_dev_onload_folds(C.byref(self._arr(u)), int(correct)))
+
+    def sweeps_in_pairs(self, u, alt, rhs, n, lo, hi):
+        """True when smooth(..., sweeps=2, lo, hi) does both sweeps in one launch (reading planes
+        lo-4 .. hi+3 of u), so that a caller narrowing its range from sweep to sweep may hand over two."""
+        return bool(self.lib.mg_dev_sweeps_in_pairs(C.byref(self._arr(u)), C.byref(self._arr(rhs)),
+                                                    (C.c_int64 * 3)(*n), lo, hi))
 
     def smooth(self, u, alt, rhs, n, c, omega, sweeps, lo, hi, second=None):
         """Returns True when the result landed in `alt`.  second = (lo2, hi2): another range of
@@ -264,15 +306,23 @@ class Comm:
             dst.copy_(h)
 
     def _halo_ops(self, slab, own, width):
+        """width: planes per side, or (rlo, slo, shi, rhi) = planes received below the owned range,
+        sent from its low end, sent from its high end, received above it (what a rank sends is what
+        its neighbour receives; a side with nothing to move is left out on both ranks)."""
         lo, hi = own
+        rlo, slo, shi, rhi = (width,) * 4 if isinstance(width, int) else width
         ops = []
         if self.rank + 1 < self.world:
-            assert slab.i0 + slab.planes - hi >= width  # halo planes stored above
-            ops.append(dist.P2POp(dist.isend, slab.rows(hi - width, hi), self.rank + 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, slab.rows(hi, hi + width), self.rank + 1, self.group))
+            assert slab.i0 + slab.planes - hi >= rhi  # halo planes stored above
+            if shi > 0:
+                ops.append(dist.P2POp(dist.isend, slab.rows(hi - shi, hi), self.rank + 1, self.group))
+            if rhi > 0:
+                ops.append(dist.P2POp(dist.irecv, slab.rows(hi, hi + rhi), self.rank + 1, self.group))
         if self.rank > 0:
-            ops.append(dist.P2POp(dist.isend, slab.rows(lo, lo + width), self.rank - 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, slab.rows(lo - width, lo), self.rank - 1, self.group))
+            if slo > 0:
+                ops.append(dist.P2POp(dist.isend, slab.rows(lo, lo + slo), self.rank - 1, self.group))
+            if rlo > 0:
+                ops.append(dist.P2POp(dist.irecv, slab.rows(lo - rlo, lo), self.rank - 1, self.group))
         self.bytes_sent += sum(o.tensor.numel() * 8 for o in ops if o.op is dist.isend)
         return ops
 
@@ -348,7 +398,8 @@ class DistSolver:
 
     H_U, H_RHS = 2, 1  # halo planes of swept fields / of right-hand sides
 
-    def __init__(self, n0, dh, depth, ops, comm, nu=None, omega=1.4, cut=None, cut_size=128, overlap=True):
+    def __init__(self, n0, dh, depth, ops, comm, nu=None, omega=1.4, cut=None, cut_size=128, overlap=True,
+                 deep_halos=True):
         self.ops, self.comm = ops, comm
         self.overlap = overlap  # run halo exchanges under the interior part of the sweeps
         self.rank, self.world = comm.rank, comm.world
@@ -359,9 +410,24 @@ class DistSolver:
         self.omega = omega
         self.coef = [ops.coef(self.dh, l) for l in range(depth + 1)]
         P, r = self.plan, self.rank
+        # deep halos on levels 1..cut-1: eps_l and R_l reach as far beyond the owned planes as all
+        # sweeps of the level do, and R_l's planes there arrive once per cycle
+        self.deep = bool(deep_halos) and P.deep_fits(self.nu)
+        if self.deep:
+            self.dfirst, self.dlast = P.deep_ranges(r, self.nu)
+            below = P.deep_ranges(r - 1, self.nu)[0] if r > 0 else None
+            above = P.deep_ranges(r + 1, self.nu)[0] if r + 1 < self.world else None
+            self.dhalo = {}
+            for l in range(1, self.cut):
+                lo, hi = P.own(l, "R", r)
+                f = P.deep_rhs(l, self.dfirst[l])
+                self.dhalo[l] = (lo - f[0], max(P.deep_rhs(l, below[l])[1] - lo, 0) if below else 0,
+                                 hi - P.deep_rhs(l, above[l])[0] if above else 0, max(f[1] - hi, 0))
 
         def slab(l, kind, halo):
             lo, hi = P.stored(l, kind, r, halo)
+            if self.deep and 1 <= l < self.cut:
+                lo, hi = self.dfirst[l] if kind == "eps" else P.deep_rhs(l, self.dfirst[l])
             d = P.dims(l, kind)
             return Slab(ops, lo, hi - lo, d[1], d[2])
 
@@ -519,6 +585,41 @@ class DistSolver:
         self.last_sum = self.comm.allreduce_sum(s)
         return self.last_sum
 
+    def _sweeps_deep(self, l, below):
+        """The nu[l] sweeps of a distributed level on deep halos: eps_l = P(eps_{l+1}) on dfirst[l], then
+        sweep s on dlast[l] widened by 2*(nu-s) planes per side.  No exchange: the planes beyond the
+        owned ones are computed here as the neighbour computes them, from R_l planes received once."""
+        P, ops = self.plan, self.ops
+        n, nu, top = P.level_n(l), self.nu[l], P.planes(l, "eps")
+        u, alt, rhs = self.eps[l], self.eps_alt[l], self.R[l]
+        below.ready()
+        rhs.ready()
+        last = self.dlast[l]
+
+        def out(s):
+            w = 2 * (nu - s)
+            return max(last[0] - w, 0), min(last[1] + w, top)
+
+        s = 1
+        if nu > 0 and ops.onload_folds(u, False):
+            assert ops.prolong_smooth(below, False, u, alt, rhs, n, self.coef[l], self.omega, *out(1)), \
+                "out-of-place sweep expected"
+            u, alt = alt, u
+            s = 2
+        else:
+            f = self.dfirst[l]
+            ops.prolong(below, u, n, f[0], min(f[1], n[0]), False)
+        while s <= nu:
+            if s + 1 <= nu and ops.sweeps_in_pairs(u, alt, rhs, n, *out(s + 1)):
+                swapped = ops.smooth(u, alt, rhs, n, self.coef[l], self.omega, 2, *out(s + 1))
+                s += 2
+            else:
+                swapped = ops.smooth(u, alt, rhs, n, self.coef[l], self.omega, 1, *out(s))
+                s += 1
+            if swapped:
+                u, alt = alt, u
+        self.eps[l], self.eps_alt[l] = u, alt
+
     def coarse_correction(self):
         """Steps 3)-5): restrict down to the cut level, all-gather it, solve the small levels (every
         rank), then (prolong, smooth) up.  Step 6), the correction of phi, is left pending for the
@@ -526,10 +627,21 @@ class DistSolver:
         P, ops, comm = self.plan, self.ops, self.comm
         for l in range(1, self.cut):
             # R_l's halo plane below feeds the restriction; both feed the sweeps' red halo planes
-            comm.exchange(self.R[l], self.own(l, "R"), self.H_RHS)
+            # (with deep halos the plane above comes later, with the others the sweeps reach)
+            comm.exchange(self.R[l], self.own(l, "R"), (self.H_RHS, 0, self.H_RHS, 0) if self.deep else self.H_RHS)
             lo, hi = self.own(l + 1, "R")
             ops.restrict27(self.R[l], self.R[l + 1], P.level_n(l), lo, hi)
         comm.allgather_planes(P, self.cut, "R", self.R[self.cut], self.cR[self.cut])
+        if self.deep:
+            # the planes of R_l the sweeps of level l reach beyond the owned ones: one message per side
+            # and level, in the order they are needed; they travel while the whole levels are solved
+            for l in range(self.cut - 1, 0, -1):
+                comm.exchange_start(self.R[l], self.own(l, "R"), self.dhalo[l])
+            self._coarse_levels()
+            for l in range(self.cut - 1, 0, -1):
+                self._sweeps_deep(l, self.ceps[self.cut] if l + 1 == self.cut else self.eps[l + 1])
+            self.correction_pending = True
+            return
         self._coarse_levels()
         # eps_cut on this rank's stored planes: a local copy out of its own whole array
         lo, hi = P.stored(self.cut, "eps", self.rank, self.H_U)
@@ -552,7 +664,7 @@ class DistSolver:
         level cut-1, and a sweep needs its input two planes further out on either side than it
         produces; a level is cut down this way when that leaves at most half of it."""
         P, L, H = self.plan, self.depth, 2
-        need = P.stored(self.cut - 1, "eps" if self.cut > 1 else "phi", self.rank, H)
+        need = self.dfirst[self.cut - 1] if self.deep else P.stored(self.cut - 1, "eps" if self.cut > 1 else "phi", self.rank, H)
         first, last = {}, {}
         for l in range(self.cut, L + 1):
             top = P.planes(l, "eps")

@@ -127,6 +127,7 @@ SYMBOLS = {
                                            C.c_double, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                            C.POINTER(C.c_int)]),
     "mg_dev_onload_folds": (C.c_int, [C.POINTER(MgDevArray), C.c_int]),
+    "mg_dev_sweeps_in_pairs": (C.c_int, [C.POINTER(MgDevArray), C.POINTER(MgDevArray), _i64x3, C.c_int64, C.c_int64]),
     "mg_dev_compute_ef": (C.c_int, [C.c_void_p, C.POINTER(MgDevArray), C.c_void_p, C.c_int64, _i64x3, _f64x3,
                                     C.c_int64, C.c_int64]),
     # slab-partitioned solve driven inside the library, one rank per GPU

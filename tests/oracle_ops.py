@@ -15,8 +15,14 @@ class OracleOps:
     """out_of_place=True makes a sweep read u and write alt, like the GPU's single-pass kernel, so
     that the solver issues sweeps as edge and interior plane ranges around the halo exchange."""
 
-    def __init__(self, out_of_place=False):
+    def __init__(self, out_of_place=False, pairs=False):
         self._oop = out_of_place
+        self._pairs = pairs and out_of_place  # two sweeps per call where the stored planes allow, like k_sweep_rb2
+
+    def sweeps_in_pairs(self, u, alt, rhs, n, lo, hi):
+        def holds(s, a, b, top):
+            return s.i0 <= max(a, 0) and s.i0 + s.planes >= min(b, top)
+        return self._pairs and holds(u, lo - 4, hi + 4, n[0]) and holds(rhs, lo - 3, hi + 3, n[0] - 1)
 
     def out_of_place(self, u):
         return self._oop
@@ -44,6 +50,18 @@ class OracleOps:
         if second:
             assert self._oop and sweeps == 1 and second[1] - second[0] == hi - lo and second[0] >= hi
             self.smooth(u, alt, rhs, n, c, omega, 1, second[0], second[1])
+        if sweeps == 2 and not second and self.sweeps_in_pairs(u, alt, rhs, n, lo, hi):
+            # both sweeps in one call, the way the GPU's pair kernel does them: planes [lo,hi) of alt
+            # from planes [lo-4, hi+4) of u, nothing else of alt written
+            a, b = max(lo - 4, u.i0), min(hi + 4, u.i0 + u.planes)
+            tmp = type(u).__new__(type(u))
+            tmp.i0, tmp.nj, tmp.nk, tmp.pitch, tmp.pending = a, u.nj, u.nk, u.pitch, None
+            tmp.t = u.rows(a, b).clone()
+            for w in (2, 0):
+                orc.lib().orc_slab_smooth_rb(C.byref(self._v(tmp)), C.byref(self._v(rhs)), (C.c_int64 * 3)(*n),
+                                             (C.c_double * 4)(*c), omega, max(lo - w, a), min(hi + w, b))
+            alt.rows(lo, hi).copy_(tmp.rows(lo, hi))
+            return True
         if self._oop and sweeps == 1:
             # planes [lo,hi) of alt = one sweep of u: run the in-place slab form on a scratch copy of
             # the planes it touches, keep only the requested planes

@@ -117,6 +117,91 @@ def test_whole_levels_cut_down_to_what_a_rank_needs(orc, tmp_path, world, n, dep
     assert min(int(np.load(tmp_path / f"first_{r}.npy")[0]) for r in range(world)) < whole
 
 
+def _deep_worker(rank, world, port, n, depth, cut, nu, cycles, out_dir, oop, deep):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multigrid_amd import dist as mgd, problem
+        from oracle_ops import OracleOps
+        N = (n, n, n)
+        s = mgd.DistSolver(N, problem.main_extents_dh(N), depth, OracleOps(bool(oop), pairs=oop == 3),
+                           mgd.Comm(defer=oop >= 2), cut=cut, nu=nu, deep_halos=deep)
+        assert s.deep == deep
+        s.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
+        s.set_phi(lambda lo, hi: np.zeros((hi - lo, n, n)))
+        l2 = s.vcycles(cycles)
+        lo, phi = s.get_phi_owned()
+        np.save(os.path.join(out_dir, f"phi_{rank}.npy"), phi)
+        np.save(os.path.join(out_dir, f"lo_{rank}.npy"), np.array([lo, s.comm.bytes_sent]))
+        if rank == 0:
+            np.save(os.path.join(out_dir, "l2.npy"), np.array([l2]))
+    finally:
+        dist.destroy_process_group()
+
+
+DEEP_CASES = [(2, 65, 3, 3, (1, 1, 1, 4), 0), (2, 65, 3, 3, (1, 1, 1, 4), 2), (2, 65, 3, 2, (2, 3, 2, 4), 1),
+              (4, 129, 4, 3, (1, 2, 1, 1, 5), 3), (3, 129, 4, 3, (1, 3, 0, 2, 5), 3), (4, 129, 4, 2, (1, 2, 3, 1, 5), 2)]
+
+
+@pytest.mark.parametrize("world,n,depth,cut,nu,oop", DEEP_CASES, ids=str)
+def test_deep_halos_equal_undivided_oracle(orc, tmp_path, world, n, depth, cut, nu, oop):
+    """Levels 1..cut-1 on deep halos: one exchange of R_l per cycle, eps_l formed on the slab widened
+    by two planes per sweep, ranges shrinking from sweep to sweep, no exchange between the sweeps.
+    oop 0: in-place operators; 1: out-of-place (on-load prolongation); 2: every exchange completed as
+    late as the schedule allows; 3: also two sweeps per call where the stored planes allow (as the
+    GPU's pair kernel).  The same bits as the undivided oracle, and as the schedule that exchanges
+    after every sweep -- with fewer messages."""
+    cycles = 3
+    runs = {}
+    for deep in (True, False):
+        out = tmp_path / str(deep)
+        out.mkdir()
+        mp.spawn(_deep_worker, args=(world, free_port(), n, depth, cut, nu, cycles, str(out), oop, deep), nprocs=world, join=True)
+        runs[deep] = out
+    N = (n, n, n)
+    want = np.zeros(N)
+    _, _, _, hist = orc.Solver(N, orc.main_extents_dh(N), depth, nu=nu).solve(want, orc.synthetic_rho(N), cycles, 0.0, rb=True)
+    for deep, out in runs.items():
+        got = np.zeros(N)
+        for r in range(world):
+            lo = int(np.load(out / f"lo_{r}.npy")[0])
+            part = np.load(out / f"phi_{r}.npy")
+            got[lo:lo + part.shape[0]] = part
+        assert_bit_equal(got, want, f"phi assembled from the slabs (deep halos: {deep})")
+        assert np.load(out / "l2.npy")[0] == pytest.approx(hist[-1], rel=1e-12)
+
+
+def test_deep_halo_ranges_nest_and_fit(mg):
+    """The arithmetic of the deep halos at the sizes of the scaling runs: every rank's ranges lie on
+    itself and its two neighbours, what one rank sends is what its neighbour receives, and a level's
+    range covers what the prolongation onto the level above reads."""
+    from multigrid_amd.dist import SlabPlan, schedule
+    for n0, depth, world, cut, fits in [(1025, 6, 8, None, True), (1025, 6, 4, None, True), (1025, 6, 2, None, True),
+                                        (2049, 7, 8, None, True), (513, 5, 8, None, True),
+                                        (513, 5, 8, 3, False),     # 16 planes of level 2 per rank, 17 needed of a neighbour
+                                        (257, 5, 2, None, False)]:  # no coarse level is distributed
+        p = SlabPlan((n0,) * 3, depth, world, cut)
+        nu = schedule(depth)
+        assert p.deep_fits(nu) == fits, (n0, world)
+        if not fits:
+            continue
+        ranges = [p.deep_ranges(r, nu) for r in range(world)]
+        for r in range(world):
+            first, last = ranges[r]
+            need = p.stored(0, "phi", r, 2)
+            for l in range(1, p.cut):
+                lo, hi = p.own(l, "eps", r)
+                assert first[l][0] <= last[l][0] <= lo and hi <= last[l][1] <= first[l][1]
+                # the prolongation onto fine plane f reads coarse plane f/2, and f/2 + 1 when f is odd
+                f = need[1] - 1
+                assert last[l][0] <= need[0] >> 1 and last[l][1] >= min((f >> 1) + 1 + (f & 1), p.planes(l, "eps"))
+                need = first[l]
+                if r + 1 < world:  # what this rank's range reaches into the next rank's planes, and back
+                    assert first[l][1] <= p.own(l, "eps", r + 1)[1]
+                    assert ranges[r + 1][0][l][0] >= lo
+
+
 def test_plan_partitions_every_level(mg):
     from multigrid_amd.dist import SlabPlan
     for n0, depth, world in [(1025, 6, 8), (1025, 6, 2), (513, 5, 4), (2049, 7, 8), (129, 3, 2)]:

@@ -14,7 +14,11 @@ from util import assert_bit_equal
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(gpu, world, n, depth, cut, body, hold_back=False, overlap=True, join_timeout=240, deep_halos=True):
+def run_ranks_with(gpu, world, n, depth, cut, body, hold_back, nu):
+    return run_ranks(gpu, world, n, depth, cut, body, hold_back, nu=nu)
+
+
+def run_ranks(gpu, world, n, depth, cut, body, hold_back=False, overlap=True, join_timeout=240, deep_halos=True, nu=None):
     """body(rank_object, rank) on `world` threads; returns their results by rank."""
     from multigrid_amd import problem
     N = (n, n, n) if isinstance(n, int) else tuple(n)
@@ -26,7 +30,7 @@ def run_ranks(gpu, world, n, depth, cut, body, hold_back=False, overlap=True, jo
         d = None
         try:
             d = gpu.DistRank(N, dh, depth, r, world, device=0, local_group=group, coarse_cut=cut, overlap=overlap,
-                             deep_halos=deep_halos)
+                             deep_halos=deep_halos, nu=nu)
             d.set_rho(lambda lo, hi: problem.synthetic_rho(N, (lo, hi)))
             d.set_phi(lambda lo, hi: np.zeros((hi - lo,) + N[1:]))
             out[r] = body(d, r)
@@ -417,6 +421,93 @@ def test_random_sweep_schedules_on_cut_down_levels(gpu, n, depth, world, cut, nu
         h.set_phi(phi0)
         assert h.vcycles(3) == pytest.approx(l2, rel=1e-12)
         assert_bit_equal(got, h.get_phi(), "phi of the slabs")
+
+
+def _undivided(gpu, n, depth, cycles, nu=None, rho=None, phi0=None):
+    from multigrid_amd import problem
+    with gpu.Handle(n, problem.main_extents_dh(n), depth, nu=nu) as h:
+        h.set_rho(problem.synthetic_rho(n) if rho is None else rho)
+        h.set_phi(np.zeros(n) if phi0 is None else phi0)
+        l2 = h.vcycles(cycles)
+        return l2, h.get_phi()
+
+
+@pytest.mark.parametrize("world,n,depth,cut,fits", [(2, 257, 5, 3, True), (3, 257, 5, 3, True), (4, 257, 5, 3, False),
+                                                    (4, 513, 5, 3, True), (2, 129, 4, 2, True), (2, 513, 5, 4, True)])
+@pytest.mark.parametrize("hold_back", [False, True], ids=["exchange_early", "exchange_late"])
+@pytest.mark.parametrize("deep_halos", [True, False], ids=["deep_halos", "exchange_every_sweep"])
+def test_deep_halos_on_coarse_distributed_levels(gpu, world, n, depth, cut, fits, hold_back, deep_halos):
+    """Levels 1..cut-1 with ONE exchange of R_l per cycle: eps_l is formed on the slab widened by two
+    planes per sweep of the level and swept on ranges that shrink from sweep to sweep (in pairs where
+    the kernels take two sweeps per launch); where a neighbour holds too few planes for that
+    (4 ranks at 257^3: 16 planes of level 2, 17 needed) the rank exchanges after every sweep instead.
+    Either way, with every exchange completed early or as late as the schedule allows, three cycles
+    end on the undivided handle's bits."""
+    if n >= 513 and (hold_back or not deep_halos):
+        pytest.skip("covered at 257^3")
+    N = (n, n, n)
+
+    def body(d, r):
+        assert d.deep_halos == (fits and deep_halos)
+        return (d.vcycles(3),) + d.get_phi_owned()
+
+    res = run_ranks(gpu, world, n, depth, cut, body, hold_back, deep_halos=deep_halos)
+    l2, want = _undivided(gpu, N, depth, 3)
+    got = np.full(N, np.nan)
+    for norm, lo, part in res:
+        assert norm == pytest.approx(l2, rel=1e-12)
+        got[lo:lo + part.shape[0]] = part
+    assert_bit_equal(got, want, "phi assembled from the slabs")
+
+
+def _deep_cases():
+    import os
+    g = np.random.default_rng(int(os.environ.get("MG_FUZZ_SEED", "20261111")) + 5)
+    out = []
+    for _ in range(6 * int(os.environ.get("MG_FUZZ_MULT", "1"))):
+        # a long first axis, few ranks, short schedules: the planes the sweeps reach lie on the neighbours
+        wide = bool(g.integers(0, 2))  # rows of 256 and more take the marching kernels and the on-load prolongation
+        n = (int(g.integers(130, 420)), int(g.integers(260, 300) if wide else g.integers(24, 200)),
+             int(g.integers(260, 300) if wide else g.integers(24, 200)))
+        deepest = 0
+        while (min(n) >> (deepest + 1)) >= 3:
+            deepest += 1
+        depth = int(g.integers(2, min(deepest, 4) + 1))
+        cut = int(g.integers(2, depth + 1))
+        nu = (int(g.integers(1, 3)),) + tuple(int(x) for x in g.integers(0, 5, size=depth - 1)) + (int(g.integers(1, 12)),)
+        out.append((n, depth, int(g.integers(2, 5)), cut, nu, bool(g.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("n,depth,world,cut,nu,hold_back", _deep_cases(), ids=str)
+def test_random_schedules_on_deep_halos(gpu, n, depth, world, cut, nu, hold_back):
+    """Random grids with a long first axis, cuts at level 2 and below and random sweep schedules (zero,
+    odd and even counts): the library decides for deep halos exactly when the plan's arithmetic says
+    that every rank finds its planes on its two neighbours, and the potential after three cycles
+    equals the undivided handle's."""
+    from multigrid_amd.dist import SlabPlan
+    try:
+        plan = SlabPlan(n, depth, world, cut)
+    except ValueError:
+        plan = None
+
+    def body(d, r):
+        assert d.deep_halos == plan.deep_fits(nu)
+        return (d.vcycles(3),) + d.get_phi_owned()
+
+    N = tuple(n)
+    try:
+        res = run_ranks_with(gpu, world, N, depth, cut, body, hold_back, nu)
+    except gpu.MgError as e:
+        assert plan is None and e.code == -1 and "planes over" in str(e)
+        return
+    assert plan is not None
+    l2, want = _undivided(gpu, N, depth, 3, nu=nu)
+    got = np.full(N, np.nan)
+    for norm, lo, part in res:
+        assert norm == pytest.approx(l2, rel=1e-12)
+        got[lo:lo + part.shape[0]] = part
+    assert_bit_equal(got, want, "phi assembled from the slabs")
 
 
 def _late_exchange_cases():

@@ -49,6 +49,7 @@ def test_slab_plans_of_the_scaling_run_equal_the_undivided_grid_at_1025(gpu, und
     def body(d, r):
         h = [d.vcycles(1) for _ in range(CYCLES)]
         lo, phi = d.get_phi_owned()
+        assert d.deep_halos  # levels 1 and 2 with one exchange of R_l per cycle: the scaling run's schedule
         return lo, d.own, d.cut, plane_checksums(phi), h
 
     res = run_ranks(gpu, world, N1, DEPTH, 0, body, hold_back, join_timeout=900)
