@@ -443,7 +443,7 @@ def run_distributed(args):
     vps = args.steps / wall
     npts = float(n) ** 3
     stats = d.stats()
-    cut, own = d.cut, d.own
+    cut, own, deep = d.cut, d.own, d.deep_halos
 
     solve = None
     if not args.no_solve:
@@ -484,7 +484,10 @@ def run_distributed(args):
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{n}^3 fp64 multigrid V{depth} cycle, red-black GS-SOR, slab-partitioned over "
                                       f"{world} GPUs (halo planes over RCCL send/recv, levels >= {cut} "
-                                      f"all-gathered and solved whole on every GPU)", "grid": n, "depth": depth, "driver": "libmg_hip mg_dist (C++)",
+                                      f"all-gathered and solved whole on every GPU"
+                                      + (f", levels 1..{cut - 1} on deep halos: one exchange of R_l per cycle" if deep else "")
+                                      + ")", "grid": n, "depth": depth, "driver": "libmg_hip mg_dist (C++)",
+                          "deep_halos": deep,
                           "note": "N=1 runs the 513^3 headline configuration; N>=2 run 1025^3 (strong scaling among N>=2)"},
                "vcycles_per_s": vps, "last_L2": l2, "roofline": roofline, "cpu_baseline": cpu, "solve": solve,
                "single_gpu_same_workload": base1, "halo_bytes_sent_rank0": stats["bytes_sent"],
