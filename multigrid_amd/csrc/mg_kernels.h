@@ -223,6 +223,9 @@ void sweep_rb_fused_onload(hipStream_t s, View uin, View uout, View rhs, View ec
 // for plane ranges too short to march along.  Same contract as sweep_rb_fused.
 void sweep_rb_tile(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c, double omega,
                    IRange r, IRange r2 = IRange{0, 0});
+// Two sweeps of planes r in one launch by tiles; u_in must hold planes [r.lo-4, r.hi+4) as far as the
+// level has them, rhs planes [r.lo-3, r.hi+3).
+void sweep_rb_tile2(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c, double omega, IRange r);
 // True when smooth_rb on an array of this shape (with a twin to write to) runs an out-of-place
 // single-pass kernel: disjoint plane ranges of one sweep are then independent launches.
 bool sweep_is_out_of_place(const View &u);

@@ -484,6 +484,14 @@ static bool use_tile_sweep() { static const int v = exp_knob("MG_EXP_NO_TILE", 0
 
 bool sweep_is_out_of_place(const View &u) { return use_fused_sweep(u) || (use_tile_sweep() && u.d[0] >= 1); }
 
+// Tiles take two sweeps per launch on planes up to this many points: there a launch is latency, and
+// three launches for five sweeps beat five.
+static int64_t tile_pair_max_area()
+{
+    static const int v = exp_knob("MG_EXP_TILE2_ROWS", 72);
+    return (int64_t)v * v;
+}
+
 bool sweeps_in_pairs(const View &u, const View &alt, const View &rhs, const int64_t n[3], IRange r)
 {
     const bool tile = alt.p && use_tile_sweep() && (!use_fused_sweep(u) || r.hi - r.lo <= tile_max_planes(u));
@@ -493,7 +501,8 @@ bool sweeps_in_pairs(const View &u, const View &alt, const View &rhs, const int6
     const auto holds = [&](const View &v, int64_t lo, int64_t hi, int64_t top) {
         return v.i0 <= (lo < 0 ? 0 : lo) && v.i_end() >= (hi > top ? top : hi);
     };
-    return fused && holds(u, r.lo - 4, r.hi + 4, n[0]) && holds(rhs, r.lo - 3, r.hi + 3, n[0] - 1);
+    const bool by_tiles = tile && u.d[1] * u.d[2] <= tile_pair_max_area();
+    return (fused || by_tiles) && holds(u, r.lo - 4, r.hi + 4, n[0]) && holds(rhs, r.lo - 3, r.hi + 3, n[0] - 1);
 }
 
 int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], Coef c,
@@ -543,7 +552,8 @@ int smooth_rb(hipStream_t s, View *u, View *alt, View rhs, const int64_t n[3], C
     for (int sw = 0; sw < sweeps; sw++) {
         launches++;
         if (pairs && sw + 1 < sweeps) {
-            sweep_rb_fused2(s, *u, *alt, rhs, n, c, omega, r);
+            if (tile) sweep_rb_tile2(s, *u, *alt, rhs, n, c, omega, r);
+            else sweep_rb_fused2(s, *u, *alt, rhs, n, c, omega, r);
             View t = *u;
             *u = *alt;
             *alt = t;

@@ -19,6 +19,12 @@
 // ([element][plane][row][pair]: consecutive lanes read consecutive words).  All index arithmetic is
 // shifts and masks.
 //
+// Two sweeps per launch (S = 2): the same with four rings -- red of sweep 1 on the block plus three
+// rings, black of sweep 1 on the block plus two, red of sweep 2 on the block plus one, black of sweep 2
+// on the block, a barrier between the phases.  A launch then owns less of what it loads (8 x 24 of
+// 16 x 32 per plane, TI of TI + 8 planes), which pays where a launch is latency and not work: the
+// levels of 65^3 and below, whose five sweeps become three launches.
+//
 // The update is the reference's expression evaluated in its order
 // (cpp/PotentialSolver.cpp:3780-3786, :3929-3935): results are bit-identical to the
 // colour-per-launch kernel and to the marching kernels.
@@ -34,15 +40,19 @@ struct alignas(16) d2 { double x, y; };
 
 __device__ __forceinline__ double pick(d2 v, int e) { return e ? v.y : v.x; }
 
-constexpr int kTileJ = 12, kTileK = 28;  // owned rows / columns of a tile; + 4 = 16 rows, 16 pairs
+// owned rows / columns of a tile that does S sweeps: the loaded 16 rows x 16 pairs minus 2 S rings
+constexpr int tile_j(int S) { return 16 - 4 * S; }
+constexpr int tile_k(int S) { return 32 - 4 * S; }
 
-template <int TI, bool FAST>
+template <int TI, bool FAST, int S = 1>
 __global__ __launch_bounds__(256) void k_sweep_tile(View uin, View uout, View rhs, int nI, int nJ, int nK, Coef c,
                                                      double omega, int tiles_j, int tiles_k, int tiles_i1, int lo1,
                                                      int hi1, int lo2, int hi2)
 {
-    constexpr int BI = TI + 4, BJ = kTileJ + 4, H = (kTileK + 4) / 2;
+    constexpr int RINGS = 2 * S, kTileJ = tile_j(S), kTileK = tile_k(S);
+    constexpr int BI = TI + 2 * RINGS, BJ = kTileJ + 2 * RINGS, H = (kTileK + 2 * RINGS) / 2;
     static_assert(BJ == 16 && H == 16, "thread mapping: 16 rows of 16 pairs");
+    static_assert(S == 1 || S == 2, "one or two sweeps per launch");
     constexpr int PLANE = BJ * H;            // pairs per plane of the region = threads
     constexpr int ELEM = BI * PLANE + 2;     // one pair element of the region, a guard word at either end
     __shared__ double su[2 * ELEM];
@@ -60,8 +70,8 @@ __global__ __launch_bounds__(256) void k_sweep_tile(View uin, View uout, View rh
         rlo = lo2;
         rhi = hi2;
     }
-    const int gi0 = rlo + ti * TI - 2, gj = tj * kTileJ - 2 + lj, gk = tk * kTileK - 2 + 2 * lkp;  // gk: the pair's even element
-    const int own_hi = min(rlo + ti * TI + TI, rhi);  // owned planes: [gi0 + 2, own_hi)
+    const int gi0 = rlo + ti * TI - RINGS, gj = tj * kTileJ - RINGS + lj, gk = tk * kTileK - RINGS + 2 * lkp;  // gk: the pair's even element
+    const int own_hi = min(rlo + ti * TI + TI, rhi);  // owned planes: [gi0 + RINGS, own_hi)
     const int uJ = (int)uin.d[1], uK = (int)uin.d[2];
     const int rJ = (int)rhs.d[1], rK = (int)rhs.d[2];
     const int ulo = (int)uin.i0, uhi = (int)uin.i_end() - 1;
@@ -85,11 +95,12 @@ __global__ __launch_bounds__(256) void k_sweep_tile(View uin, View uout, View rh
     // element x at gk, y at gk + 1
     const bool jin = gj >= 1 && gj <= nJ - 2;
     const bool xin = jin && gk >= 1 && gk <= nK - 2, yin = jin && gk + 1 >= 1 && gk + 1 <= nK - 2;
-    // red phase: the block plus one ring = rows 1..14, columns 1..30 of the region
-    const bool xr = xin && lj >= 1 && lj <= BJ - 2 && lkp >= 1, yr = yin && lj >= 1 && lj <= BJ - 2 && lkp <= H - 2;
-    // black phase: the block = rows 2..13, columns 2..29
-    const bool own = lj >= 2 && lj <= BJ - 3 && lkp >= 1 && lkp <= H - 2;
-    const bool xb = xin && own, yb = yin && own;
+    // phase p (0: red of the first sweep, 1: its black, ...) updates the region minus p + 1 rings: rows
+    // and columns p+1 .. 14-p / 30-p of the region (the pair's x at column 2 lkp, y at 2 lkp + 1)
+    const auto xok = [&](int ring) { return xin && lj >= ring && lj <= BJ - 1 - ring && 2 * lkp >= ring && 2 * lkp <= 2 * H - 1 - ring; };
+    const auto yok = [&](int ring) { return yin && lj >= ring && lj <= BJ - 1 - ring && 2 * lkp + 1 >= ring && 2 * lkp + 1 <= 2 * H - 1 - ring; };
+    // the block itself: the region minus all rings (whole pairs: RINGS is even)
+    const bool own = lj >= RINGS && lj <= BJ - 1 - RINGS && lkp >= RINGS / 2 && lkp <= H - 1 - RINGS / 2;
 
     double *X = su + 1, *Y = su + ELEM + 1;   // element images; the guard words take the reads off either end
     const int at = lj * H + lkp;
@@ -135,33 +146,40 @@ __global__ __launch_bounds__(256) void k_sweep_tile(View uin, View uout, View rh
             if (publish) (e[t] ? Y : X)[q * PLANE + at] = un;
         }
     };
-    phase(std::integral_constant<int, 1>{}, std::integral_constant<int, BI - 1>{}, 0, xr, yr, true);
+    phase(std::integral_constant<int, 1>{}, std::integral_constant<int, BI - 1>{}, 0, xok(1), yok(1), true);
     __syncthreads();
-    phase(std::integral_constant<int, 2>{}, std::integral_constant<int, BI - 2>{}, 1, xb, yb, false);
+    phase(std::integral_constant<int, 2>{}, std::integral_constant<int, BI - 2>{}, 1, xok(2), yok(2), S > 1);
+    if constexpr (S > 1) {
+        __syncthreads();
+        phase(std::integral_constant<int, 3>{}, std::integral_constant<int, BI - 3>{}, 0, xok(3), yok(3), true);
+        __syncthreads();
+        phase(std::integral_constant<int, 4>{}, std::integral_constant<int, BI - 4>{}, 1, xok(4), yok(4), false);
+    }
 
     if (own && gj < uJ && gk < uK) {
         double *o = uout.p + (int64_t)gj * uout.sj + gk;
 #pragma unroll
-        for (int q = 2; q < BI - 2; q++) {
+        for (int q = RINGS; q < BI - RINGS; q++) {
             const int gi = gi0 + q;
             if (gi < own_hi) *reinterpret_cast<d2 *>(o + (int64_t)(gi - (int)uout.i0) * uout.si) = v[q];
         }
     }
 }
 
-template <int TI>
+template <int TI, int S = 1>
 void launch_tile(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c, double omega, IRange r,
                  IRange r2)
 {
+    constexpr int kTileJ = tile_j(S), kTileK = tile_k(S);
     const int tiles_j = (int)((uin.d[1] + kTileJ - 1) / kTileJ), tiles_k = (int)((uin.d[2] + kTileK - 1) / kTileK);
     const int tiles_i1 = (int)((r.hi - r.lo + TI - 1) / TI);
     const int tiles_i2 = r2.hi > r2.lo ? (int)((r2.hi - r2.lo + TI - 1) / TI) : 0;
     const unsigned grid = (unsigned)(tiles_j * tiles_k) * (unsigned)(tiles_i1 + tiles_i2);
     if (c.fast)
-        hipLaunchKernelGGL((k_sweep_tile<TI, true>), dim3(grid), dim3(256), 0, s, uin, uout, rhs, (int)n[0], (int)n[1],
+        hipLaunchKernelGGL((k_sweep_tile<TI, true, S>), dim3(grid), dim3(256), 0, s, uin, uout, rhs, (int)n[0], (int)n[1],
                            (int)n[2], c, omega, tiles_j, tiles_k, tiles_i1, (int)r.lo, (int)r.hi, (int)r2.lo, (int)r2.hi);
     else
-        hipLaunchKernelGGL((k_sweep_tile<TI, false>), dim3(grid), dim3(256), 0, s, uin, uout, rhs, (int)n[0], (int)n[1],
+        hipLaunchKernelGGL((k_sweep_tile<TI, false, S>), dim3(grid), dim3(256), 0, s, uin, uout, rhs, (int)n[0], (int)n[1],
                            (int)n[2], c, omega, tiles_j, tiles_k, tiles_i1, (int)r.lo, (int)r.hi, (int)r2.lo, (int)r2.hi);
 }
 
@@ -185,6 +203,19 @@ void sweep_rb_tile(hipStream_t s, View uin, View uout, View rhs, const int64_t n
     if (ti == 2) launch_tile<2>(s, uin, uout, rhs, n, c, omega, r, r2);
     else if (ti == 4) launch_tile<4>(s, uin, uout, rhs, n, c, omega, r, r2);
     else launch_tile<8>(s, uin, uout, rhs, n, c, omega, r, r2);
+}
+
+// TWO full red-black sweeps of planes r of u_in into u_out by 3-D tiles in one launch.  u_in must hold
+// planes [r.lo-4, r.hi+4) as far as they exist in the level, rhs planes [r.lo-3, r.hi+3).
+void sweep_rb_tile2(hipStream_t s, View uin, View uout, View rhs, const int64_t n[3], Coef c, double omega, IRange r)
+{
+    if (r.hi <= r.lo) return;
+    static const int shape = exp_knob("MG_EXP_TILE2", 0);
+    // planes per tile, by measurement as for the single sweep
+    int ti = (r.hi - r.lo <= 2 || uin.d[1] * uin.d[2] <= 40 * 40) ? 2 : 4;
+    if (shape == 2 || shape == 4) ti = shape;
+    if (ti == 2) launch_tile<2, 2>(s, uin, uout, rhs, n, c, omega, r, IRange{0, 0});
+    else launch_tile<4, 2>(s, uin, uout, rhs, n, c, omega, r, IRange{0, 0});
 }
 
 }  // namespace mgk
