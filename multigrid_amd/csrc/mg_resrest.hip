@@ -26,21 +26,22 @@ namespace {
 
 struct alignas(16) d2 { double x, y; };
 
-// Value of the lane below (lane - 1) in the wave; lane 0 keeps its own.
+// Value of lane - 1 / lane + 1 of the wave.  Lanes 0 / 63, which have no such neighbour, get 0 (a
+// shift that kept their own value would cost a register copy per half): they sit at a window-edge
+// column, as do the lanes at the ends of a 32-lane row, which receive another row's value -- nothing
+// computed from either is ever used.
 __device__ __forceinline__ double lane_left(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-
-// Value of the lane above (lane + 1) in the wave; lane 63 keeps its own.
 __device__ __forceinline__ double lane_right(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
