@@ -323,7 +323,7 @@ def slab_profiled_traffic(n, world):
     fine planes) from the committed rocprofv3 counter summary of that share, measured with the rank
     alone on one GPU (tools/profile_slab.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes,
     FETCH_SIZE doubled).  None where no summary of this configuration is committed."""
-    name = {(1025, 8): "r03b_slab_mid", (1025, 4): "r03b_slab_w4", (1025, 2): "r03b_slab_w2",
+    name = {(1025, 8): "r03h_slab_mid", (1025, 4): "r03b_slab_w4", (1025, 2): "r03b_slab_w2",
             (2049, 8): "r03b_slab2049_mid"}.get((n, world))
     path = os.path.join(ROOT, "profiles", f"{name}_summary.json") if name else None
     if not path or not os.path.exists(path):
