@@ -1,9 +1,9 @@
 #!/bin/bash
 # Kernel-by-kernel timeline (start, end, queue) of one V-cycle of one rank's share of the slab
-# solve, from a rocprofv3 kernel trace of tools/slab_rank_time.py.  usage: tools/slab_timeline.sh <tag> [case]
+# solve, from a rocprofv3 kernel trace of tools/slab_rank_time.py.  usage: [SIZE=2049] tools/slab_timeline.sh <tag> [case]
 tag=${1:-slabtl}; case_=${2:-8:3}
 out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 tools/slab_rank_time.py --cases $case_ > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 tools/slab_rank_time.py --size ${SIZE:-1025} --cases $case_ > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
 python3 - $out <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/trace/*/*_kernel_trace.csv")[0]
