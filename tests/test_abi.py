@@ -137,3 +137,11 @@ def test_slab_entry_points_validate_before_launching(mg):
     assert lib.mg_dev_onload_folds(C.byref(_arr(mg, None, 40, 200, 200, 0)), 1) == 1   # correction: from 128 rows
     assert lib.mg_dev_onload_folds(C.byref(_arr(mg, None, 40, 200, 200, 0)), 0) == 0   # prolongation: from 256
     assert lib.mg_dev_onload_folds(C.byref(_arr(mg, None, 40, 300, 300, 0)), 0) == 1
+    # two sweeps in one launch: planes four beyond the range must be stored (eps arrays: one node more than the level)
+    i3 = lambda a, b, c_: (C.c_int64 * 3)(a, b, c_)
+    pairs = lambda u, rhs, n_, lo, hi: lib.mg_dev_sweeps_in_pairs(C.byref(u), C.byref(rhs), n_, lo, hi)
+    assert pairs(_arr(mg, None, 301, 301, 301, 0), _arr(mg, None, 300, 300, 300, 0), i3(300, 300, 300), 0, 301) == 1  # whole array
+    assert pairs(_arr(mg, None, 48, 301, 301, 100), _arr(mg, None, 46, 300, 300, 101), i3(300, 300, 300), 104, 144) == 1  # slab, four halo planes
+    assert pairs(_arr(mg, None, 44, 301, 301, 102), _arr(mg, None, 42, 300, 300, 103), i3(300, 300, 300), 104, 144) == 0  # slab, two halo planes
+    assert pairs(_arr(mg, None, 65, 65, 65, 0), _arr(mg, None, 64, 64, 64, 0), i3(64, 64, 64), 0, 65) == 1     # small level: by tiles
+    assert pairs(_arr(mg, None, 129, 129, 129, 0), _arr(mg, None, 128, 128, 128, 0), i3(128, 128, 128), 40, 80) == 0  # 40 planes of 129^2: tiles, one sweep each
