@@ -11,7 +11,8 @@
 //   (4) MultiGrid V1-V5 are this library's solvers, the others are refused;
 //   --b selects the reference's "B" solver variant (7-point restriction);
 //   --vti file writes phi, rho and ef as VTK ImageData in the reference's ASCII format
-//   --gpus 0,1,2,3 splits the grid into slabs over those GPUs (an ordinal may repeat);
+//   --gpus 0,1,2,3 splits the grid into slabs over those GPUs (an ordinal may repeat); --cut L names
+//   the first level every GPU holds whole (default: the first with at most 128 planes);
 //   --pageable keeps the World's fields in ordinary memory (default: page-locked blocks);
 //   --again repeats solve() twice more: once with world.phi untouched, once after the driver has
 //   reset world.phi to zero; --assume-untouched lets the solver skip the upload of a world.phi
@@ -54,7 +55,7 @@ int main(int argc, char **argv)
     const char *dump = nullptr, *dump_ef = nullptr, *vti = nullptr;
     bool variant_b = false, again = false, pageable = false, menu = false, assume_untouched = false, invalidate = false;
     const char *edit = nullptr;
-    int max_it = 0;
+    int max_it = 0, cut = 0;
     std::vector<int> gpus;
     int pos = 0;
     for (int a = 1; a < argc; a++) {
@@ -68,6 +69,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--edit") && a + 1 < argc) edit = argv[++a];
         else if (!strcmp(argv[a], "--max-it") && a + 1 < argc) max_it = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--pageable")) pageable = true;
+        else if (!strcmp(argv[a], "--cut") && a + 1 < argc) cut = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--gpus") && a + 1 < argc) {
             for (char *t = strtok(argv[++a], ","); t; t = strtok(nullptr, ",")) gpus.push_back(atoi(t));
         }
@@ -127,7 +129,7 @@ int main(int argc, char **argv)
                 }
         const int its = max_it > 0 ? max_it : (depth == 0 && !menu ? 100000 : 10000);
         MultiGridSolverHIP *mg = depth == 0       ? new GaussSeidelSolverHIP(world, its, tol)
-                                 : gpus.size() > 1 ? new MultiGridSolverHIP(world, its, tol, depth, gpus)
+                                 : gpus.size() > 1 ? new MultiGridSolverHIP(world, its, tol, depth, gpus, cut)
                                                    : new MultiGridSolverHIP(world, its, tol, depth, 0, variant_b);
         mg->setAssumePhiUntouched(assume_untouched);
         PotentialSolver *solver = mg;  // used through the base pointer, like the reference driver

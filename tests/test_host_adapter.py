@@ -277,14 +277,17 @@ def test_driver_writes_vti_of_the_solution(box, gpu, orc, tmp_path):
 
 
 @pytest.mark.gpu
-def test_multi_gpu_solver_behind_the_same_interface(box, gpu, tmp_path):
+@pytest.mark.parametrize("n,depth,tol,slabs", [("129", "3", "1e-6", ["--gpus", "0,0,0"]),
+                                               # levels 1 and 2 partitioned, on deep halos (one exchange of R_l per cycle)
+                                               ("257", "5", "1e-2", ["--gpus", "0,0", "--cut", "3"])], ids=["129", "257_deep_halos"])
+def test_multi_gpu_solver_behind_the_same_interface(box, gpu, tmp_path, n, depth, tol, slabs):
     """MultiGridSolverHIP(world, max_it, tol, depth, {0, 0, 0}): three slabs (here all on GPU 0) behind
     PotentialSolver::solve() give the single-GPU solver's potential bit for bit; computeEF()
     differentiates each slab on its GPU and agrees too."""
     outs = []
-    for extra in ([], ["--gpus", "0,0,0"]):
+    for extra in ([], slabs):
         phi, ef = tmp_path / f"phi{len(extra)}.bin", tmp_path / f"ef{len(extra)}.bin"
-        p = subprocess.run([BOX, "129", "3", "1e-6", "--dump", str(phi), "--dump-ef", str(ef)] + extra,
+        p = subprocess.run([BOX, n, depth, tol, "--dump", str(phi), "--dump-ef", str(ef)] + extra,
                            capture_output=True, text=True)
         assert p.returncode == 0, p.stderr
         outs.append((np.fromfile(phi), np.fromfile(ef), [l for l in p.stdout.splitlines() if "converged=" in l][0].split()[:2]))
