@@ -460,6 +460,27 @@ def test_deep_halos_on_coarse_distributed_levels(gpu, world, n, depth, cut, fits
     assert_bit_equal(got, want, "phi assembled from the slabs")
 
 
+@pytest.mark.parametrize("n,depth,world,cut,nu", [((2049, 24, 28), 3, 16, 3, None),      # sixteen ranks, 32 planes of level 2 each
+                                                  ((1025, 40, 300), 3, 5, 3, (2, 4, 3, 7)),  # unequal shares, the fine level swept twice
+                                                  ((513, 300, 56), 4, 3, 2, (1, 6, 1, 1, 9))], ids=str)
+def test_deep_halos_with_many_ranks_and_unequal_shares(gpu, n, depth, world, cut, nu):
+    """Deep halos where every rank but the outer two has two neighbours to fetch from and to serve,
+    where the shares differ by a unit of 2^cut planes, and where the fine level needs several sweeps
+    (its exchanges after every sweep remain): every exchange held back, three cycles, the undivided
+    handle's bits."""
+    def body(d, r):
+        assert d.deep_halos
+        return (d.vcycles(3),) + d.get_phi_owned()
+
+    res = run_ranks(gpu, world, n, depth, cut, body, hold_back=True, nu=nu)
+    l2, want = _undivided(gpu, n, depth, 3, nu=nu)
+    got = np.full(n, np.nan)
+    for norm, lo, part in res:
+        assert norm == pytest.approx(l2, rel=1e-12)
+        got[lo:lo + part.shape[0]] = part
+    assert_bit_equal(got, want, "phi assembled from the slabs")
+
+
 def _deep_cases():
     import os
     g = np.random.default_rng(int(os.environ.get("MG_FUZZ_SEED", "20261111")) + 5)
