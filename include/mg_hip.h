@@ -320,7 +320,9 @@ int mg_dev_sweep_out_of_place(const mg_dev_array *u);
  * The sweep may be out of place: alt has u's shape; *result_in_alt = 1 when the result
  * landed in alt (the caller swaps its references).  Out-of-place sweeps read planes
  * [lo-2, hi+2) of u as far as they exist, so with halos two planes wide one sweep needs
- * one halo exchange.  sweeps > 1 is meant for arrays held whole on one GPU.
+ * one halo exchange.  sweeps > 1 runs the sweeps one after the other, all on [lo,hi) -- for arrays
+ * held whole on one GPU -- except that two sweeps go into ONE launch where
+ * mg_dev_sweeps_in_pairs says so (it then reads planes [lo-4, hi+4) of u).
  * [lo2,hi2) (empty when lo2 == hi2) is a second range, as long as the first and above it, swept
  * in the same launch -- the planes next to the other slab neighbour; it needs sweeps == 1 and
  * the out-of-place kernel (mg_dev_sweep_out_of_place). */
