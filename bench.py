@@ -66,8 +66,8 @@ def profiled_traffic(kind):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=0, help="fine grid nodes per axis (default 513)")
     ap.add_argument("--depth", type=int, default=0, help="coarse grids (default: 5 at 513)")
     ap.add_argument("--cpu-cycles", type=int, default=3, help="cycles of the CPU baseline sample (0 = skip)")
