@@ -23,7 +23,10 @@
  * which is not installed, and stand-in headers are not allowed).  The oracle is
  * cross-checked in tests/test_oracle_known_answers.py against the residual-norm
  * histories that the structural survey recorded from the compiled reference
- * (7 significant digits, 41^3 V2 / 129^3 V3 / 257^3 V5 / 513^3 V5).
+ * (7 significant digits, 41^3 V2 / 129^3 V3 / 257^3 V5 / 513^3 V5), and in
+ * tests/test_oracle_second_transcription.py against a second transcription of
+ * the reference's loops made independently of this file (plain Python, V1..V5,
+ * non-cubic grids): bit for bit in phi, every R_l and eps_l and every norm.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
  * this file; nothing in the product path links or calls it.
