@@ -273,3 +273,96 @@ def test_c_oracle_equals_a_second_transcription_of_the_reference(orc, n, dh, cyc
         ok_a2, cyc_a2, _, _ = first2.solve(pa, rho.copy(), 50, tol)
         assert ok_a2 and ok_b2 and cyc_a2 == len(hist_b2) == 3
         assert_bit_equal(pa, pb, "phi at the stopping iteration")
+
+
+def test_field_gauss_seidel_and_seven_point_restriction_second_transcription(orc):
+    """The rows next to the V-cycle, transcribed a second time the same way: E = -grad(phi)
+    (cpp/PotentialSolver.cpp:418-458), GaussSeidelSolver::solve() (:235-291: one lexicographic SOR
+    sweep per iteration, the interior residual norm tested when it % 25 == 0) and the "B" classes'
+    restriction (:704-715)."""
+    g = np.random.default_rng(77)
+    n = (7, 9, 11)
+    ni, nj, nk = n
+    dh = (0.013, 0.017, 0.011)
+    phi = g.uniform(-1, 1, n)
+    # -- computeEF
+    dx, dy, dz = dh
+    ef = np.zeros(n + (3,))
+    for i in range(ni):
+        for j in range(nj):
+            for k in range(nk):
+                if i == 0:
+                    ef[i][j][k][0] = -(-3 * phi[i][j][k] + 4 * phi[i + 1][j][k] - phi[i + 2][j][k]) / (2 * dx)
+                elif i == ni - 1:
+                    ef[i][j][k][0] = -(phi[i - 2][j][k] - 4 * phi[i - 1][j][k] + 3 * phi[i][j][k]) / (2 * dx)
+                else:
+                    ef[i][j][k][0] = -(phi[i + 1][j][k] - phi[i - 1][j][k]) / (2 * dx)
+                if j == 0:
+                    ef[i][j][k][1] = -(-3 * phi[i][j][k] + 4 * phi[i][j + 1][k] - phi[i][j + 2][k]) / (2 * dy)
+                elif j == nj - 1:
+                    ef[i][j][k][1] = -(phi[i][j - 2][k] - 4 * phi[i][j - 1][k] + 3 * phi[i][j][k]) / (2 * dy)
+                else:
+                    ef[i][j][k][1] = -(phi[i][j + 1][k] - phi[i][j - 1][k]) / (2 * dy)
+                if k == 0:
+                    ef[i][j][k][2] = -(-3 * phi[i][j][k] + 4 * phi[i][j][k + 1] - phi[i][j][k + 2]) / (2 * dz)
+                elif k == nk - 1:
+                    ef[i][j][k][2] = -(phi[i][j][k - 2] - 4 * phi[i][j][k - 1] + 3 * phi[i][j][k]) / (2 * dz)
+                else:
+                    ef[i][j][k][2] = -(phi[i][j][k + 1] - phi[i][j][k - 1]) / (2 * dz)
+    assert_bit_equal(orc.compute_ef(phi.copy(), dh), ef, "E")
+
+    # -- the seven-point restriction of the "B" classes
+    R = g.uniform(-1, 1, (9, 12, 13))
+    Rc = np.zeros(tuple(a // 2 for a in R.shape))
+    for i in range(0, R.shape[0] - 1, 2):
+        for j in range(0, R.shape[1] - 1, 2):
+            for k in range(0, R.shape[2] - 1, 2):
+                if i == 0 or j == 0 or k == 0:
+                    Rc[i // 2][j // 2][k // 2] = R[i][j][k]
+                else:
+                    Rc[i // 2][j // 2][k // 2] = (R[i - 1][j][k] + 2 * R[i][j][k] + R[i + 1][j][k] +
+                                                  R[i][j - 1][k] + 2 * R[i][j][k] + R[i][j + 1][k] +
+                                                  R[i][j][k - 1] + 2 * R[i][j][k] + R[i][j][k + 1]) / 12.0
+    assert_bit_equal(orc.restrict7(R.copy()), Rc, "seven-point restriction")
+
+    # -- GaussSeidelSolver::solve()
+    rho = g.uniform(-1, 1, n) * EPS_0 * 1e3
+    u0 = np.zeros(n)
+    u0[1:-1, 1:-1, 1:-1] = g.uniform(-1, 1, tuple(a - 2 for a in n))
+
+    def gs(u, max_it, tol):
+        idx2, idy2, idz2 = 1.0 / (dh[0] * dh[0]), 1.0 / (dh[1] * dh[1]), 1.0 / (dh[2] * dh[2])
+        L2 = 0.0
+        for it in range(max_it):
+            for i in range(1, ni - 1):
+                for j in range(1, nj - 1):
+                    for k in range(1, nk - 1):
+                        new = (rho[i][j][k] / EPS_0 +
+                               idx2 * (u[i - 1][j][k] + u[i + 1][j][k]) +
+                               idy2 * (u[i][j - 1][k] + u[i][j + 1][k]) +
+                               idz2 * (u[i][j][k - 1] + u[i][j][k + 1])) / (2 * idx2 + 2 * idy2 + 2 * idz2)
+                        u[i][j][k] = u[i][j][k] + 1.4 * (new - u[i][j][k])
+            if it % 25 == 0:
+                total = 0.0
+                for i in range(1, ni - 1):
+                    for j in range(1, nj - 1):
+                        for k in range(1, nk - 1):
+                            r = (-u[i][j][k] * (2 * idx2 + 2 * idy2 + 2 * idz2) +
+                                 rho[i][j][k] / EPS_0 +
+                                 idx2 * (u[i - 1][j][k] + u[i + 1][j][k]) +
+                                 idy2 * (u[i][j - 1][k] + u[i][j + 1][k]) +
+                                 idz2 * (u[i][j][k - 1] + u[i][j][k + 1]))
+                            total += r * r
+                L2 = math.sqrt(total / (ni * nj * nk))
+                if L2 < tol:
+                    return True, it, L2
+        return False, max_it, L2
+
+    for max_it, tol in ((60, 0.0), (400, 1e-3)):
+        ub, ua = u0.copy(), u0.copy()
+        ok_b, it_b, l2_b = gs(ub, max_it, tol)
+        ok_a, its_a, l2_a = orc.gs_solve(ua, rho.copy(), dh, max_it, tol)
+        assert ok_a == ok_b and l2_a == l2_b
+        assert_bit_equal(ua, ub, "phi after Gauss-Seidel")
+        if ok_b:  # the sweep count the oracle reports: iterations run, the stopping one included
+            assert its_a == it_b + 1
