@@ -260,6 +260,11 @@ def test_vti_writer_format(tmp_path):
     comps, lines = arrays["NodeVol"]
     cell = 0.2 * 0.1 * 0.1
     assert comps == 1 and np.isclose(lines[0][0], cell / 8) and np.isclose(lines[2][1 * ni + 1], cell)
+    # every node: the cell volume halved once per wall the node lies on (cpp/World.cpp:74-85)
+    for k in range(nk):
+        want = [cell * 0.5 ** ((i in (0, ni - 1)) + (j in (0, nj - 1)) + (k in (0, nk - 1)))
+                for j in range(nj) for i in range(ni)]
+        assert np.allclose(lines[k], want, rtol=1e-5, atol=0)  # 6 significant digits in the file
 
 
 @pytest.mark.gpu
