@@ -444,6 +444,17 @@ int mg_dist_plan(mg_dist *d, int32_t *cut, int64_t own[2], int64_t stored_phi[2]
  * of mg_dist_config.no_overlap is clear; the results are the same bits either way.  No counterpart
  * in the reference. */
 int mg_dist_deep_halos(mg_dist *d, int32_t *deep);
+/* The same decision and the plane counts behind it from the configuration alone (base.n, base.depth,
+ * base.nu, rank, world, coarse_cut, no_overlap are read; no device, communicator or group is
+ * touched): *deep and *cut as a rank created from `cfg` reports them; own = the planes of R_level
+ * the rank owns; on deep halos and for level in 1..cut-1, first / last = the planes of eps_level the
+ * rank forms before the level's first sweep and holds after its last, and halo = the planes of
+ * R_level {received below own, sent from own's low end, sent from own's high end, received above
+ * own} in the one exchange per cycle (zeros otherwise).  What a rank sends one way is what its
+ * neighbour receives: a caller can check the whole group's message sizes without a GPU.  Any
+ * output pointer may be null.  No counterpart in the reference. */
+int mg_dist_exchange_plan(const mg_dist_config *cfg, int32_t level, int32_t *deep, int32_t *cut, int64_t own[2],
+                          int64_t first[2], int64_t last[2], int32_t halo[4]);
 /* Dense host planes [lo,hi) of the global arrays, rows of nk doubles; any sub-range of the stored
  * planes, so a rank never needs its whole slab in host memory.  rho is stored as rho/EPS_0. */
 int mg_dist_set_rho_planes(mg_dist *d, int64_t lo, int64_t hi, const double *dense);

@@ -257,6 +257,26 @@ struct Halo {
     static Halo both(int w) { return Halo{w, w, w, w}; }
 };
 
+// The one exchange of R_l per cycle on deep halos: what this rank receives is what its ranges reach
+// beyond the owned planes; what it sends is what its neighbours' ranges reach into them.
+Halo deep_halo(const Plan &P, int rank, int l, const int *nu)
+{
+    IRange last[MG_MAX_LEVELS], first[MG_MAX_LEVELS], below[MG_MAX_LEVELS], above[MG_MAX_LEVELS];
+    P.deep_ranges(rank, nu, last, first);
+    const IRange o = P.own(l, false, rank), f = P.deep_rhs(l, first[l]);
+    Halo h{(int)(o.lo - f.lo), 0, 0, (int)(f.hi > o.hi ? f.hi - o.hi : 0)};
+    if (rank > 0) {
+        P.deep_ranges(rank - 1, nu, last, below);
+        const IRange fb = P.deep_rhs(l, below[l]);
+        h.slo = (int)(fb.hi > o.lo ? fb.hi - o.lo : 0);
+    }
+    if (rank + 1 < P.world) {
+        P.deep_ranges(rank + 1, nu, last, above);
+        h.shi = (int)(o.hi - P.deep_rhs(l, above[l]).lo);
+    }
+    return h;
+}
+
 // Planes [v.i0, v.i0 + v.d[0]) of a level's array on this rank's GPU.
 struct Slab {
     View v{};
@@ -1162,21 +1182,7 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
     if (d->deep) {
         const Plan &P = d->plan;
         P.deep_ranges(cfg->rank, base.nu, d->dlast, d->dfirst);
-        // what this rank receives is what its ranges reach beyond the owned planes; what it sends is
-        // what its neighbours' ranges reach into them
-        IRange lastn[MG_MAX_LEVELS], below[MG_MAX_LEVELS], above[MG_MAX_LEVELS];
-        if (cfg->rank > 0) P.deep_ranges(cfg->rank - 1, base.nu, lastn, below);
-        if (cfg->rank + 1 < cfg->world) P.deep_ranges(cfg->rank + 1, base.nu, lastn, above);
-        for (int l = 1; l < d->cut; l++) {
-            const IRange o = P.own(l, false, cfg->rank), f = P.deep_rhs(l, d->dfirst[l]);
-            Halo h{(int)(o.lo - f.lo), 0, 0, (int)(f.hi > o.hi ? f.hi - o.hi : 0)};
-            if (cfg->rank > 0) {
-                const IRange fb = P.deep_rhs(l, below[l]);
-                h.slo = (int)(fb.hi > o.lo ? fb.hi - o.lo : 0);
-            }
-            if (cfg->rank + 1 < cfg->world) h.shi = (int)(o.hi - P.deep_rhs(l, above[l]).lo);
-            d->dhalo[l] = h;
-        }
+        for (int l = 1; l < d->cut; l++) d->dhalo[l] = deep_halo(P, cfg->rank, l, base.nu);
     }
     d->n_nodes = (double)base.n[0] * (double)base.n[1] * (double)base.n[2];
     for (int a = 0; a < 3; a++) d->dh[a] = base.dh[a];
@@ -1275,6 +1281,35 @@ int mg_dist_deep_halos(mg_dist *d, int32_t *deep)
 {
     if (!d || !deep) FAIL(MG_ERR_INVALID, "null argument");
     *deep = d->deep ? 1 : 0;
+    return MG_OK;
+}
+
+int mg_dist_exchange_plan(const mg_dist_config *cfg, int32_t level, int32_t *deep, int32_t *cut, int64_t own[2],
+                          int64_t first[2], int64_t last[2], int32_t halo[4])
+{
+    if (!cfg) FAIL(MG_ERR_INVALID, "null configuration");
+    if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) FAIL(MG_ERR_INVALID, "rank %d outside a world of %d", cfg->rank, cfg->world);
+    if (cfg->base.depth < 1 || cfg->base.depth >= MG_MAX_LEVELS) FAIL(MG_ERR_INVALID, "depth %d outside 1..%d", cfg->base.depth, MG_MAX_LEVELS - 1);
+    Plan P;
+    TRY(P.init(cfg->base.n, cfg->base.depth, cfg->world, cfg->coarse_cut));
+    const bool is_deep = (cfg->no_overlap & 2) == 0 && P.deep_fits(cfg->base.nu);
+    if (deep) *deep = is_deep ? 1 : 0;
+    if (cut) *cut = P.cut;
+    if (level < 1 || level > P.cut) FAIL(MG_ERR_INVALID, "level %d outside the partitioned levels 1..%d", level, P.cut);
+    const IRange o = P.own(level, false, cfg->rank);
+    if (own) { own[0] = o.lo; own[1] = o.hi; }
+    IRange f{0, 0}, l{0, 0};
+    Halo h{0, 0, 0, 0};
+    if (is_deep && level < P.cut) {
+        IRange lasts[MG_MAX_LEVELS], firsts[MG_MAX_LEVELS];
+        P.deep_ranges(cfg->rank, cfg->base.nu, lasts, firsts);
+        f = firsts[level];
+        l = lasts[level];
+        h = deep_halo(P, cfg->rank, level, cfg->base.nu);
+    }
+    if (first) { first[0] = f.lo; first[1] = f.hi; }
+    if (last) { last[0] = l.lo; last[1] = l.hi; }
+    if (halo) { halo[0] = h.rlo; halo[1] = h.slo; halo[2] = h.shi; halo[3] = h.rhi; }
     return MG_OK;
 }
 

@@ -148,6 +148,8 @@ SYMBOLS = {
     "mg_dist_abort": (C.c_int, [C.c_void_p]),
     "mg_dist_stats": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_uint64)]),
     "mg_dist_deep_halos": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "mg_dist_exchange_plan": (C.c_int, [C.POINTER(MgDistConfig), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.c_int64 * 2, C.c_int64 * 2, C.c_int64 * 2, C.c_int32 * 4]),
 }
 
 _lib = None
@@ -465,6 +467,25 @@ class LocalGroup:
             self._g = None
 
     __del__ = close
+
+
+def dist_exchange_plan(n, depth, rank, world, level, coarse_cut=0, nu=None, deep_halos=True, variant_b=False):
+    """mg_dist_exchange_plan: what rank `rank` of `world` exchanges on `level` once per cycle, from
+    the configuration alone (no device).  Returns a dict with deep, cut, own, first, last and
+    halo = (received below, sent from the low end, sent from the high end, received above)."""
+    n = tuple(int(a) for a in n)
+    dc = MgDistConfig()
+    dc.base = default_config(n, (1.0, 1.0, 1.0), depth, 0, variant_b=variant_b) if variant_b else \
+        default_config(n, (1.0, 1.0, 1.0), depth, 0)
+    if nu is not None:
+        for l, v in enumerate(nu):
+            dc.base.nu[l] = v
+    dc.rank, dc.world, dc.coarse_cut, dc.no_overlap = rank, world, coarse_cut, 0 if deep_halos else 2
+    deep, cut = C.c_int32(0), C.c_int32(0)
+    own, first, last, halo = (C.c_int64 * 2)(), (C.c_int64 * 2)(), (C.c_int64 * 2)(), (C.c_int32 * 4)()
+    _check(load().mg_dist_exchange_plan(C.byref(dc), level, C.byref(deep), C.byref(cut), own, first, last, halo))
+    return {"deep": bool(deep.value), "cut": cut.value, "own": tuple(own), "first": tuple(first),
+            "last": tuple(last), "halo": tuple(halo)}
 
 
 class DistRank:

@@ -261,3 +261,60 @@ def test_slab_forms_reduce_to_whole_array_forms(orc):
     orc.lib().orc_slab_prolong(C.byref(orc.view(ec, ec.shape[2], 0)), C.byref(orc.view(got, n[2], 0)),
                                (C.c_int64 * 3)(*n), 0, n[0], 0)
     assert_bit_equal(got, want, "slab prolong")
+
+
+def test_library_message_sizes_match_between_neighbours_and_the_python_twin(mg):
+    """What the C++ rank driver sends one way over RCCL must be what the neighbour posts a receive
+    for (a mismatch is a hang on a multi-GPU node, and the in-process transport of the one-GPU tests
+    cannot show it: there the receiver alone fixes the count).  mg_dist_exchange_plan gives every rank's
+    counts from the configuration alone, so the whole group is checked here without a GPU: pairwise
+    agreement, received planes inside the stored range and on the neighbour's own planes, and
+    equality with multigrid_amd/dist.py, whose counts the gloo runs above exercise for real."""
+    from multigrid_amd.dist import SlabPlan, schedule
+    cases = [(1025, 6, w, 0, None) for w in (2, 3, 4, 5, 6, 7, 8)] + \
+            [(2049, 7, 8, 0, None), (2049, 7, 8, 5, None), (513, 5, 8, 0, None), (513, 5, 4, 3, None), (513, 5, 3, 3, None),
+             (1025, 6, 8, 4, None), (1025, 6, 8, 4, [1, 1, 9, 2, 5, 5, 50]), (1025, 6, 5, 3, [2, 7, 3, 5, 5, 5, 50]),
+             (257, 4, 2, 3, [1, 3, 2, 5, 50]), (513, 5, 8, 3, None), (257, 5, 2, 0, None)]
+    checked = 0
+    for n0, depth, world, cut, nu in cases:
+        N = (n0, n0 - 32, n0) if n0 == 513 else (n0,) * 3
+        p = SlabPlan(N, depth, world, cut or None)
+        nus = list(nu) if nu else list(schedule(depth))
+        fits = p.deep_fits(nus)
+        plans = {}
+        for r in range(world):
+            for l in range(1, p.cut + 1):
+                plans[r, l] = mg.dist_exchange_plan(N, depth, r, world, l, coarse_cut=cut, nu=nu)
+                assert plans[r, l]["deep"] == fits and plans[r, l]["cut"] == p.cut, (n0, world, cut)
+                assert plans[r, l]["own"] == tuple(p.own(l, "R", r))
+        off = mg.dist_exchange_plan(N, depth, 0, world, 1, coarse_cut=cut, nu=nu, deep_halos=False)
+        assert not off["deep"] and off["halo"] == (0, 0, 0, 0)
+        if not fits:
+            assert all(v["halo"] == (0, 0, 0, 0) for v in plans.values())
+            continue
+        for r in range(world):
+            first, last = p.deep_ranges(r, nus)
+            for l in range(1, p.cut):
+                me = plans[r, l]
+                rlo, slo, shi, rhi = me["halo"]
+                lo, hi = me["own"]
+                assert me["first"] == tuple(first[l]) and me["last"] == tuple(last[l])
+                # the twin's own counts (DistSolver computes them the same way from its plan)
+                f = p.deep_rhs(l, first[l])
+                assert (rlo, rhi) == (lo - f[0], max(f[1] - hi, 0))
+                if r + 1 < world:
+                    up = plans[r + 1, l]
+                    assert shi == up["halo"][0] and rhi == up["halo"][1], (n0, world, l, r)
+                    assert 0 <= rhi <= up["own"][1] - up["own"][0] and 0 < shi <= hi - lo
+                else:
+                    assert (shi, rhi) == (0, 0)
+                if r == 0:
+                    assert (rlo, slo) == (0, 0)
+                checked += 1
+            # the level that is gathered whole has nothing to exchange in this scheme
+            assert plans[r, p.cut]["halo"] == (0, 0, 0, 0)
+    assert checked > 100
+    with pytest.raises(mg.MgError):
+        mg.dist_exchange_plan((1025,) * 3, 6, 8, 8, 1)      # rank outside the world
+    with pytest.raises(mg.MgError):
+        mg.dist_exchange_plan((1025,) * 3, 6, 0, 8, 5)      # level below the cut
