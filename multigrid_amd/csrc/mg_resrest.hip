@@ -227,38 +227,39 @@ __global__ __launch_bounds__(NT) void k_residual_restrict(View phi, View b, View
                         const int J = tj * TJC + Jl;
                         const int r = 2 * Jl + 2;
 #define PAIR(di, dj) (*reinterpret_cast<const d2 *>(&((di) < 0 ? A : (di) == 0 ? B : C)[r + (dj)][2 * l]))
+                        // (a term w * x with w = 2, 4, 8 is exact, so fma(w, x, v) rounds once, like v + w * x)
                         double v;
                         // dk = -1: the odd column left of the pair
                         v = lane_left(PAIR(-1, -1).y);
-                        v = v + 2 * lane_left(PAIR(0, -1).y);
+                        v = __builtin_fma(2.0, lane_left(PAIR(0, -1).y), v);
                         v = v + lane_left(PAIR(1, -1).y);
-                        v = v + 2 * lane_left(PAIR(-1, 0).y);
-                        v = v + 4 * lane_left(PAIR(0, 0).y);
-                        v = v + 2 * lane_left(PAIR(1, 0).y);
+                        v = __builtin_fma(2.0, lane_left(PAIR(-1, 0).y), v);
+                        v = __builtin_fma(4.0, lane_left(PAIR(0, 0).y), v);
+                        v = __builtin_fma(2.0, lane_left(PAIR(1, 0).y), v);
                         v = v + lane_left(PAIR(-1, 1).y);
-                        v = v + 2 * lane_left(PAIR(0, 1).y);
+                        v = __builtin_fma(2.0, lane_left(PAIR(0, 1).y), v);
                         v = v + lane_left(PAIR(1, 1).y);
                         // dk = 0 (pair.x) while keeping pair.y for dk = +1
                         const d2 q0 = PAIR(-1, -1), q1 = PAIR(0, -1), q2 = PAIR(1, -1), q3 = PAIR(-1, 0), q4 = PAIR(0, 0),
                                  q5 = PAIR(1, 0), q6 = PAIR(-1, 1), q7 = PAIR(0, 1), q8 = PAIR(1, 1);
-                        v = v + 2 * q0.x;
-                        v = v + 4 * q1.x;
-                        v = v + 2 * q2.x;
-                        v = v + 4 * q3.x;
-                        v = v + 8 * q4.x;
-                        v = v + 4 * q5.x;
-                        v = v + 2 * q6.x;
-                        v = v + 4 * q7.x;
-                        v = v + 2 * q8.x;
+                        v = __builtin_fma(2.0, q0.x, v);
+                        v = __builtin_fma(4.0, q1.x, v);
+                        v = __builtin_fma(2.0, q2.x, v);
+                        v = __builtin_fma(4.0, q3.x, v);
+                        v = __builtin_fma(8.0, q4.x, v);
+                        v = __builtin_fma(4.0, q5.x, v);
+                        v = __builtin_fma(2.0, q6.x, v);
+                        v = __builtin_fma(4.0, q7.x, v);
+                        v = __builtin_fma(2.0, q8.x, v);
                         // dk = +1
                         v = v + q0.y;
-                        v = v + 2 * q1.y;
+                        v = __builtin_fma(2.0, q1.y, v);
                         v = v + q2.y;
-                        v = v + 2 * q3.y;
-                        v = v + 4 * q4.y;
-                        v = v + 2 * q5.y;
+                        v = __builtin_fma(2.0, q3.y, v);
+                        v = __builtin_fma(4.0, q4.y, v);
+                        v = __builtin_fma(2.0, q5.y, v);
                         v = v + q6.y;
-                        v = v + 2 * q7.y;
+                        v = __builtin_fma(2.0, q7.y, v);
                         v = v + q8.y;
 #undef PAIR
                         v = v * 0.015625;  // == v / 64.0 exactly (power of two)
