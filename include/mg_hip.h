@@ -476,6 +476,17 @@ int mg_dist_sync(mg_dist *d);
  * a call -- it is how a supervisor releases the ranks of a group one of which has failed.  A rank
  * whose own collective call fails does this to itself.  Only mg_dist_destroy is useful afterwards. */
 int mg_dist_abort(mg_dist *d);
+/* MG_TRANSPORT_NONE only (other ranks report *count = 0): the record of the communication calls the
+ * rank would have made over RCCL since it was created, built from the same message lists the RCCL
+ * transport issues.  An entry is five numbers {what, peer, array, lo, hi}: what = 0 a halo exchange
+ * begins (lo, hi = the owned planes it is around), 4 an all-gather begins (lo, hi = the rank's share),
+ * 1 / 2 a send to / a receive from `peer` of the global planes [lo, hi) within that call, 3 an
+ * all-reduce of one double; array = 16 * level + {0 phi, 1 its out-of-place twin, 2 rho, 3 R, 4 eps,
+ * 5 its twin, 6 / 7 / 8 the whole-level R, eps and twin}.  Up to `capacity` entries are copied,
+ * *count is the number recorded.  With the records of all ranks of a world (taken one rank at a time,
+ * on one GPU) a caller can check that every send meets its receive: same call, same planes, same
+ * array.  No counterpart in the reference. */
+int mg_dist_comm_log(mg_dist *d, int64_t *entries, int64_t capacity, int64_t *count);
 /* Device time of the last vcycles/solve call and bytes this rank has sent so far. */
 int mg_dist_stats(mg_dist *d, double *last_ms, uint64_t *bytes_sent);
 

@@ -281,6 +281,7 @@ Halo deep_halo(const Plan &P, int rank, int l, const int *nu)
 struct Slab {
     View v{};
     // a halo exchange into this slab that has been started and not yet waited for
+    int tag = 0;  // which array of which level this is (16 * level + an array number): the same on every rank
     bool pending = false;
     hipEvent_t done = nullptr;  // RCCL transport: recorded on the communication stream
     IRange held_own{0, 0};      // in-process transport holding the exchange back: what to do at the wait
@@ -292,9 +293,53 @@ struct Slab {
 
 // ---------------------------------------------------------------------------- transports
 
+// One point-to-point transfer of whole planes: global planes [lo, hi) of a level's array, to or
+// from the rank `peer`.
+struct Msg {
+    int peer;
+    bool send;
+    int64_t lo, hi;
+};
+
+// The transfers of one halo exchange `h` around the owned planes `own` (a side with nothing to move
+// is left out -- on both ranks, since one rank's send count is its neighbour's receive count).
+int halo_msgs(int rank, int world, IRange own, Halo h, Msg out[4])
+{
+    int n = 0;
+    if (rank + 1 < world) {
+        if (h.shi > 0) out[n++] = Msg{rank + 1, true, own.hi - h.shi, own.hi};
+        if (h.rhi > 0) out[n++] = Msg{rank + 1, false, own.hi, own.hi + h.rhi};
+    }
+    if (rank > 0) {
+        if (h.slo > 0) out[n++] = Msg{rank - 1, true, own.lo, own.lo + h.slo};
+        if (h.rlo > 0) out[n++] = Msg{rank - 1, false, own.lo - h.rlo, own.lo};
+    }
+    return n;
+}
+
+// The transfers of an all-gather of a level's owned planes: this rank's share to every other rank,
+// every other rank's share from it (grouped send/recv pairs rather than ncclAllGather: the ranks'
+// shares differ in length).
+void gather_msgs(const Plan &p, int l, bool eps, int rank, std::vector<Msg> &out)
+{
+    const IRange me = p.own(l, eps, rank);
+    out.clear();
+    for (int r = 0; r < p.world; r++) {
+        if (r == rank) continue;
+        const IRange o = p.own(l, eps, r);
+        out.push_back(Msg{r, true, me.lo, me.hi});
+        out.push_back(Msg{r, false, o.lo, o.hi});
+    }
+}
+
+// Record of a rank's communication calls, five numbers each: {what, peer, array tag, lo, hi}.
+enum { LOG_HALO = 0, LOG_SEND = 1, LOG_RECV = 2, LOG_ALLREDUCE = 3, LOG_GATHER = 4 };
+
 struct Transport {
     int rank = 0, world = 1;
     uint64_t bytes_sent = 0;
+    // kept by the transport that moves nothing: what the rank would have sent and received
+    virtual const std::vector<int64_t> *comm_log() const { return nullptr; }
     // Set by abort(): a rank of the group has failed.  Every later operation returns MG_ERR_COMM at
     // once instead of queueing transfers no peer will ever match.
     std::atomic<bool> aborted{false};
@@ -432,17 +477,18 @@ struct RcclTransport : Transport {
         if (!s.done) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         TRY(order_after_compute(compute));
         const size_t plane = (size_t)s.v.si;
-        // (a side with nothing to move is left out on both ranks: this rank's count is its neighbour's)
+        Msg msgs[4];
+        const int n_msgs = halo_msgs(rank, world, own, h, msgs);
         NCCL_TRY(api->GroupStart());
-        if (rank + 1 < world) {
-            if (h.shi > 0) NCCL_TRY(api->Send(s.plane(own.hi - h.shi), h.shi * plane, ncclDouble, rank + 1, comm, cs));
-            if (h.rhi > 0) NCCL_TRY(api->Recv(s.plane(own.hi), h.rhi * plane, ncclDouble, rank + 1, comm, cs));
-            bytes_sent += h.shi * plane * 8;
-        }
-        if (rank > 0) {
-            if (h.slo > 0) NCCL_TRY(api->Send(s.plane(own.lo), h.slo * plane, ncclDouble, rank - 1, comm, cs));
-            if (h.rlo > 0) NCCL_TRY(api->Recv(s.plane(own.lo - h.rlo), h.rlo * plane, ncclDouble, rank - 1, comm, cs));
-            bytes_sent += h.slo * plane * 8;
+        for (int k = 0; k < n_msgs; k++) {
+            const Msg &m = msgs[k];
+            const size_t count = (size_t)(m.hi - m.lo) * plane;
+            if (m.send) {
+                NCCL_TRY(api->Send(s.plane(m.lo), count, ncclDouble, m.peer, comm, cs));
+                bytes_sent += count * 8;
+            } else {
+                NCCL_TRY(api->Recv(s.plane(m.lo), count, ncclDouble, m.peer, comm, cs));
+            }
         }
         NCCL_TRY(api->GroupEnd());
         HIP_TRY(hipEventRecord(s.done, cs));
@@ -484,14 +530,16 @@ struct RcclTransport : Transport {
         TRY(copy_planes(full, mine.v, me, compute));
         if (world == 1) return MG_OK;
         TRY(order_after_compute(compute));
-        // grouped send/recv pairs rather than ncclAllGather: the ranks' shares differ in length
+        std::vector<Msg> msgs;
+        gather_msgs(p, l, eps, rank, msgs);
         NCCL_TRY(api->GroupStart());
-        for (int r = 0; r < world; r++) {
-            if (r == rank) continue;
-            const IRange o = p.own(l, eps, r);
-            NCCL_TRY(api->Send(mine.plane(me.lo), (size_t)(me.hi - me.lo) * mine.v.si, ncclDouble, r, comm, cs));
-            NCCL_TRY(api->Recv(full.plane(o.lo), (size_t)(o.hi - o.lo) * full.v.si, ncclDouble, r, comm, cs));
-            bytes_sent += (uint64_t)(me.hi - me.lo) * mine.v.si * 8;
+        for (const Msg &m : msgs) {
+            if (m.send) {
+                NCCL_TRY(api->Send(mine.plane(m.lo), (size_t)(m.hi - m.lo) * mine.v.si, ncclDouble, m.peer, comm, cs));
+                bytes_sent += (uint64_t)(m.hi - m.lo) * mine.v.si * 8;
+            } else {
+                NCCL_TRY(api->Recv(full.plane(m.lo), (size_t)(m.hi - m.lo) * full.v.si, ncclDouble, m.peer, comm, cs));
+            }
         }
         NCCL_TRY(api->GroupEnd());
         return compute_waits(compute);
@@ -637,13 +685,46 @@ struct LocalTransport : Transport {
 // Every launch, its plane ranges and the order of the streams' dependencies are those of the rank
 // in the full world; halo planes keep whatever they hold and the sums stay local, so the numbers
 // a solve produces mean nothing.
+//
+// It keeps a record of the calls the RCCL transport would have made in its place -- built from the
+// same message lists (halo_msgs, gather_msgs) -- so that the records of all ranks of a world, taken
+// one rank at a time on one GPU, can be checked against each other: every send has its receive on
+// the peer, in the same call, for the same planes of the same array.
 struct SoloTransport : Transport {
-    int start(Slab &, IRange, Halo, hipStream_t) override { return MG_OK; }
+    static constexpr size_t kMaxLog = 5 * 100000;
+    std::vector<int64_t> log;
+    const std::vector<int64_t> *comm_log() const override { return &log; }
+    void note(int what, int peer, int tag, int64_t lo, int64_t hi)
+    {
+        if (log.size() + 5 > kMaxLog) return;
+        const int64_t e[5] = {what, peer, tag, lo, hi};
+        log.insert(log.end(), e, e + 5);
+    }
+    int start(Slab &s, IRange own, Halo h, hipStream_t) override
+    {
+        if (world == 1) return MG_OK;
+        Msg msgs[4];
+        const int n_msgs = halo_msgs(rank, world, own, h, msgs);
+        note(LOG_HALO, -1, s.tag, own.lo, own.hi);
+        for (int k = 0; k < n_msgs; k++) note(msgs[k].send ? LOG_SEND : LOG_RECV, msgs[k].peer, s.tag, msgs[k].lo, msgs[k].hi);
+        return MG_OK;
+    }
     int finish(Slab &, hipStream_t) override { return MG_OK; }
-    int allreduce(double *, hipStream_t) override { return MG_OK; }
+    int allreduce(double *, hipStream_t) override
+    {
+        if (world > 1) note(LOG_ALLREDUCE, -1, -1, 0, 1);
+        return MG_OK;
+    }
     int sum_ready(hipStream_t) override { return MG_OK; }
     int allgather(const Plan &p, int l, bool eps, const Slab &mine, Slab &full, hipStream_t compute) override
     {
+        if (world > 1) {
+            std::vector<Msg> msgs;
+            gather_msgs(p, l, eps, rank, msgs);
+            const IRange me = p.own(l, eps, rank);
+            note(LOG_GATHER, -1, mine.tag, me.lo, me.hi);
+            for (const Msg &m : msgs) note(m.send ? LOG_SEND : LOG_RECV, m.peer, m.send ? mine.tag : full.tag, m.lo, m.hi);
+        }
         return copy_planes(full, mine.v, p.own(l, eps, rank), compute);
     }
 };
@@ -1244,6 +1325,19 @@ int mg_dist_create(const mg_dist_config *cfg, mg_dist **out)
         CREATE_TRY(d->alloc(&d->ceps[l], l, true, IRange{0, P.planes(l, true)}));
         CREATE_TRY(d->alloc(&d->ceps_alt[l], l, true, IRange{0, P.planes(l, true)}));
     }
+    // array tags: 16 * level + {0 phi, 1 its out-of-place twin, 2 right-hand side, 3 R, 4 eps, 5 its twin,
+    // 6 whole R, 7 whole eps, 8 its twin}
+    d->phi.tag = 0;
+    d->phi_alt.tag = 1;
+    d->b.tag = 2;
+    for (int l = 1; l <= d->L; l++) {
+        d->R[l].tag = 16 * l + 3;
+        d->eps[l].tag = 16 * l + 4;
+        d->eps_alt[l].tag = 16 * l + 5;
+        d->cR[l].tag = 16 * l + 6;
+        d->ceps[l].tag = 16 * l + 7;
+        d->ceps_alt[l].tag = 16 * l + 8;
+    }
     {
         // partial sums of the fine residual: the owned range, or interior + edges
         const IRange o = d->own(0, false);
@@ -1281,6 +1375,17 @@ int mg_dist_deep_halos(mg_dist *d, int32_t *deep)
 {
     if (!d || !deep) FAIL(MG_ERR_INVALID, "null argument");
     *deep = d->deep ? 1 : 0;
+    return MG_OK;
+}
+
+int mg_dist_comm_log(mg_dist *d, int64_t *entries, int64_t capacity, int64_t *count)
+{
+    if (!d || !count || (capacity > 0 && !entries)) FAIL(MG_ERR_INVALID, "null argument");
+    const std::vector<int64_t> *log = d->tr ? d->tr->comm_log() : nullptr;
+    const int64_t have = log ? (int64_t)(log->size() / 5) : 0;
+    *count = have;
+    const int64_t take = have < capacity ? have : capacity;
+    if (take > 0) memcpy(entries, log->data(), (size_t)take * 5 * sizeof(int64_t));
     return MG_OK;
 }
 

@@ -148,6 +148,7 @@ SYMBOLS = {
     "mg_dist_abort": (C.c_int, [C.c_void_p]),
     "mg_dist_stats": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_uint64)]),
     "mg_dist_deep_halos": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "mg_dist_comm_log": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64)]),
     "mg_dist_exchange_plan": (C.c_int, [C.POINTER(MgDistConfig), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.c_int64 * 2, C.c_int64 * 2, C.c_int64 * 2, C.c_int32 * 4]),
 }
@@ -530,6 +531,15 @@ class DistRank:
         if getattr(self, "_d", None):
             load().mg_dist_destroy(self._d)
             self._d = None
+
+    def comm_log(self):
+        """mg_dist_comm_log: the transfers a rank created with alone=True would have made, as a list of
+        (what, peer, array, lo, hi)."""
+        count = C.c_int64(0)
+        _check(load().mg_dist_comm_log(self._d, None, 0, C.byref(count)))
+        buf = (C.c_int64 * (5 * max(count.value, 1)))()
+        _check(load().mg_dist_comm_log(self._d, buf, count.value, C.byref(count)))
+        return [tuple(buf[5 * e:5 * e + 5]) for e in range(count.value)]
 
     def _planes(self, f, rng, of_planes, chunk):
         lo, hi = rng

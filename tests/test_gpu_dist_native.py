@@ -562,3 +562,106 @@ def test_overlapped_schedule_with_every_exchange_held_back_on_random_grids(gpu, 
         l2 = h.vcycles(2)
         assert_bit_equal(got, h.get_phi(), "phi assembled from the slabs")
     assert all(r[0] == pytest.approx(l2, rel=1e-12) for r in res)
+
+
+def _calls(log):
+    """A rank's record split into its calls: [(what, array, (lo, hi), [(send?, peer, array, lo, hi), ...])]."""
+    calls = []
+    for what, peer, tag, lo, hi in log:
+        if what in (0, 3, 4):
+            calls.append((what, tag, (lo, hi), []))
+        else:
+            assert what in (1, 2) and calls and calls[-1][0] in (0, 4), "a transfer outside a call"
+            calls[-1][3].append((what == 1, peer, tag, lo, hi))
+    return calls
+
+
+def _check_records(logs):
+    """Every rank made the same calls in the same order, and within each call every send has exactly
+    one receive on its peer for the same planes of the same array (an all-gather sends from the
+    slab R_l, array 16 l + 3, into the whole-level copy, 16 l + 6)."""
+    world = len(logs)
+    per_rank = [_calls(l) for l in logs]
+    shape = [(what, tag) for what, tag, _, _ in per_rank[0]]
+    for r in range(world):
+        assert [(what, tag) for what, tag, _, _ in per_rank[r]] == shape, f"rank {r} makes other calls than rank 0"
+    widest = 0
+    for c, (what, tag) in enumerate(shape):
+        sends, recvs = {}, {}
+        for r in range(world):
+            _, _, (olo, ohi), msgs = per_rank[r][c]
+            for send, peer, mtag, lo, hi in msgs:
+                assert 0 <= peer < world and peer != r and lo < hi
+                book = sends if send else recvs
+                key = (r, peer) if send else (peer, r)   # (from, to)
+                assert key not in book, f"call {c}: two transfers {key} in one group"
+                book[key] = (mtag, lo, hi)
+                if what == 0:
+                    assert abs(peer - r) == 1 and mtag == tag
+                    if send:
+                        assert olo <= lo and hi <= ohi, "a rank sends planes it does not own"
+                    else:
+                        assert hi <= olo or lo >= ohi, "a rank receives planes it owns"
+                    widest = max(widest, hi - lo)
+                else:
+                    assert (lo, hi) == (olo, ohi) if send else True
+        assert set(sends) == set(recvs), f"call {c} ({what}, array {tag}): unmatched transfers {set(sends) ^ set(recvs)}"
+        for key, (stag, lo, hi) in sends.items():
+            rtag, rlo, rhi = recvs[key]
+            assert (lo, hi) == (rlo, rhi), f"call {c}: {key} sends planes {lo}..{hi}, the peer expects {rlo}..{rhi}"
+            assert rtag == (stag if what == 0 else stag + 3)
+        if what == 4:
+            assert len(sends) == world * (world - 1)
+    return shape, widest
+
+
+@pytest.mark.parametrize("n,depth,world,cut,nu,overlap,deep", [
+    (1025, 6, 8, 0, None, True, True),      # the scaling run's plans
+    (1025, 6, 4, 0, None, True, True),
+    (1025, 6, 2, 0, None, True, True),
+    (513, 5, 8, 0, None, True, True),
+    (257, 5, 3, 3, None, True, True),       # unequal shares, two partitioned coarse levels
+    (257, 5, 3, 3, None, False, True),      # exchanges after whole sweeps
+    (257, 5, 3, 3, None, True, False),      # an exchange after every sweep on every level
+    (257, 4, 2, 3, [2, 3, 4, 5, 50], True, True),
+    ((129, 40, 40), 3, 5, 2, None, True, True),
+], ids=str)
+def test_every_send_of_every_rank_has_its_receive(gpu, n, depth, world, cut, nu, overlap, deep):
+    """The RCCL transport cannot run between the ranks of a world on the one GPU of the test box, and
+    the in-process transport that stands in for it is driven by the receiver alone.  Here every
+    rank of the world runs by itself (MG_TRANSPORT_NONE) -- two cycles, a solve and computeEF -- and
+    records the calls it would have made over RCCL, built from the message lists the RCCL transport
+    issues; the records are then matched against each other: same calls in the same order on every
+    rank (a collective or a grouped exchange that one rank skips is a hang), and per call every send
+    met by one receive for the same global planes of the same array (a count that differs is a hang
+    or silent corruption)."""
+    from multigrid_amd import problem
+    N = (n, n, n) if isinstance(n, int) else tuple(n)
+    dh = problem.main_extents_dh(N)
+    logs, deep_seen = [], None
+    for r in range(world):
+        d = gpu.DistRank(N, dh, depth, r, world, device=0, coarse_cut=cut, nu=nu, overlap=overlap, deep_halos=deep, alone=True)
+        try:
+            zeros = lambda lo, hi: np.zeros((hi - lo,) + N[1:])  # noqa: E731 -- the numbers mean nothing here
+            d.set_rho(zeros)
+            d.set_phi(zeros)
+            d.vcycles(2)
+            d.solve(2, 0.0)
+            gpu._check(gpu.load().mg_dist_compute_ef(d._d))   # (E stays on the device)
+            logs.append(d.comm_log())
+            assert deep_seen in (None, d.deep_halos)
+            deep_seen = d.deep_halos
+        finally:
+            d.close()
+    shape, widest = _check_records(logs)
+    kinds = [what for what, _ in shape]
+    assert kinds.count(3) == 4                # one norm per cycle: 2 + 2
+    assert kinds.count(4) == 4                # one all-gather of R_cut per cycle
+    assert (0, 0) in shape or (0, 1) in shape  # the fine grid's halo planes
+    if deep_seen:
+        # one exchange of R_l per cycle and partitioned coarse level, more than one sweep's planes wide
+        cut_used = [tag // 16 for what, tag in shape if what == 4][0]
+        assert cut_used >= 2 and widest > 2
+        assert not any(what == 0 and tag % 16 in (4, 5) for what, tag in shape), "eps_l is never exchanged on deep halos"
+    elif cut and cut > 1:
+        assert any(what == 0 and tag % 16 in (4, 5) for what, tag in shape)
