@@ -1393,8 +1393,14 @@ int mg_dist_exchange_plan(const mg_dist_config *cfg, int32_t level, int32_t *dee
                           int64_t first[2], int64_t last[2], int32_t halo[4])
 {
     if (!cfg) FAIL(MG_ERR_INVALID, "null configuration");
-    if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) FAIL(MG_ERR_INVALID, "rank %d outside a world of %d", cfg->rank, cfg->world);
-    if (cfg->base.depth < 1 || cfg->base.depth >= MG_MAX_LEVELS) FAIL(MG_ERR_INVALID, "depth %d outside 1..%d", cfg->base.depth, MG_MAX_LEVELS - 1);
+    // the checks of mg_dist_create that the plan depends on
+    if (cfg->world < 1 || cfg->world > MG_MAX_GPUS || cfg->rank < 0 || cfg->rank >= cfg->world)
+        FAIL(MG_ERR_INVALID, "rank %d / world %d out of range", cfg->rank, cfg->world);
+    if (cfg->base.depth < 1 || cfg->base.depth >= MG_MAX_LEVELS) FAIL(MG_ERR_INVALID, "depth %d out of range 1..%d", cfg->base.depth, MG_MAX_LEVELS - 1);
+    for (int a = 0; a < 3; a++)
+        if (cfg->base.n[a] < 3 || cfg->base.n[a] > 65535) FAIL(MG_ERR_INVALID, "n[%d]=%lld out of range", a, (long long)cfg->base.n[a]);
+    for (int l = 0; l <= cfg->base.depth; l++)
+        if (cfg->base.nu[l] < 0 || cfg->base.nu[l] > 100000) FAIL(MG_ERR_INVALID, "nu[%d]=%d out of range", l, cfg->base.nu[l]);
     Plan P;
     TRY(P.init(cfg->base.n, cfg->base.depth, cfg->world, cfg->coarse_cut));
     const bool is_deep = (cfg->no_overlap & 2) == 0 && P.deep_fits(cfg->base.nu);
