@@ -20,7 +20,8 @@
  *   - the smoother is red-black Gauss-Seidel/SOR, colour (i+j+k)&1 == 0 first,
  *     with the reference's update formula and omega; every other operator
  *     reproduces the reference's arithmetic bit for bit (same association
- *     order, true divisions, no FMA contraction).
+ *     order, correctly rounded divisions, no FMA contraction that would drop a
+ *     rounding: only products that are exact, by 2, 4 or 8, are fused).
  */
 #ifndef MG_HIP_H
 #define MG_HIP_H
