@@ -665,3 +665,52 @@ def test_every_send_of_every_rank_has_its_receive(gpu, n, depth, world, cut, nu,
         assert not any(what == 0 and tag % 16 in (4, 5) for what, tag in shape), "eps_l is never exchanged on deep halos"
     elif cut and cut > 1:
         assert any(what == 0 and tag % 16 in (4, 5) for what, tag in shape)
+
+
+def test_records_match_on_random_plans(gpu):
+    """The same matching of every rank's record on random grids, depths, cuts, world sizes up to
+    eight, sweep schedules with zeros, and both exchange policies: small grids, so that many plans
+    (also those the library must refuse) are seen."""
+    import os
+    from multigrid_amd import problem
+    g = np.random.default_rng(int(os.environ.get("MG_FUZZ_SEED", "20261111")) + 9)
+    ran = deep = refused = 0
+    for _ in range(40 * int(os.environ.get("MG_FUZZ_MULT", "1"))):
+        N = (int(g.integers(17, 260)), int(g.integers(9, 70)), int(g.integers(9, 70)))
+        deepest = 0
+        while (min(N) >> (deepest + 1)) >= 3:
+            deepest += 1
+        depth = int(g.integers(1, min(deepest, 5) + 1))
+        cut = int(g.integers(0, depth + 1))
+        world = int(g.integers(2, 9))
+        nu = [int(g.integers(1, 3))] + [int(x) for x in g.integers(0, 5, size=depth - 1)] + [int(g.integers(1, 8))]
+        overlap, deep_halos = bool(g.integers(0, 2)), bool(g.integers(0, 4))
+        dh = problem.main_extents_dh(N)
+        logs, flags = [], set()
+        try:
+            for r in range(world):
+                d = gpu.DistRank(N, dh, depth, r, world, device=0, coarse_cut=cut, nu=nu, overlap=overlap,
+                                 deep_halos=deep_halos, alone=True)
+                try:
+                    zeros = lambda lo, hi: np.zeros((hi - lo,) + N[1:])  # noqa: E731
+                    d.set_rho(zeros)
+                    d.set_phi(zeros)
+                    d.vcycles(2)
+                    gpu._check(gpu.load().mg_dist_compute_ef(d._d))
+                    logs.append(d.comm_log())
+                    flags.add(d.deep_halos)
+                finally:
+                    d.close()
+        except gpu.MgError as e:
+            assert e.code == -1 and "planes over" in str(e) and not logs, (N, depth, world, cut, str(e))
+            refused += 1
+            continue
+        assert len(flags) == 1, "the ranks of one world disagree about deep halos"
+        try:
+            _check_records(logs)
+        except AssertionError as e:
+            raise AssertionError(f"{N} depth {depth} world {world} cut {cut} nu {nu} overlap {overlap} deep {deep_halos}: {e}")
+        ran += 1
+        deep += flags.pop()
+    print(f"plans matched: {ran} ({deep} on deep halos), refused: {refused}")
+    assert ran >= 15 and refused >= 1 and deep >= 3, (ran, refused, deep)
